@@ -1,0 +1,37 @@
+"""pytest configuration: registers the ``gpu`` marker and shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def row_errors(W, Wref):
+    """Parity metric of SURVEY.md 8c: per-row max|dW| / max|Wref| and global rel-L2."""
+    W = np.asarray(W)
+    Wref = np.asarray(Wref)
+    num = np.abs(W - Wref).max(axis=-1)
+    den = np.abs(Wref).max(axis=-1)
+    per_row = num / np.where(den == 0, 1, den)
+    l2 = np.linalg.norm((W - Wref).ravel()) / max(np.linalg.norm(Wref.ravel()), 1e-300)
+    return per_row, l2
