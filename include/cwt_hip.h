@@ -1,0 +1,131 @@
+/* cwt_hip.h -- C ABI of libcwt_hip.so, the MI355X (gfx950) engine behind
+ * pycwt.cwt() / pycwt.icwt().
+ *
+ * The reference (regeirk/pycwt) has no native code; its only plug-in seam for
+ * this path is the `helpers.fft` module object plus `helpers.fft_kwargs`
+ * (pycwt/helpers.py:6-30), used by wavelet.cwt at pycwt/wavelet.py:91-106.
+ * This library replaces what flows through that seam -- forward FFT of the
+ * signal, the per-scale filter bank sqrt(2*pi*s/dt)*conj(psi_ft(s*w)), the
+ * batched inverse FFT -- and the icwt column reduction (wavelet.py:169-170),
+ * with hand-written HIP kernels.  Each entry point names the reference lines
+ * it stands in for.  INTEGRATION.md shows the ctypes binding a pycwt
+ * maintainer would add.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a
+ * negative CWT_E* code on failure (message via cwt_last_error(), thread
+ * local); no exception crosses the ABI; buffers are caller-owned; `*_dev`
+ * pointers are device addresses on the plan's GPU, `*_host` pointers are host
+ * addresses.  A plan is not thread-safe; distinct plans may be used from
+ * distinct threads / streams.  All launches of a plan go to the stream set by
+ * cwt_plan_set_stream (default: the null stream).
+ *
+ * Complex data are interleaved (re, im) pairs of the plan's real type:
+ * precision 64 -> double/complex128, precision 32 -> float/complex64.
+ */
+#ifndef CWT_HIP_H
+#define CWT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CWT_OK 0
+#define CWT_EINVAL (-1)  /* bad argument                                   */
+#define CWT_EHIP (-2)    /* a HIP runtime call failed                      */
+#define CWT_ENOMEM (-3)  /* device or host allocation failed               */
+#define CWT_ENODEV (-4)  /* no usable GPU                                  */
+
+/* mother wavelets with a built-in Fourier-domain profile (pycwt/mothers.py) */
+#define CWT_MORLET 0 /* psi_ft: mothers.py:26-28,  param = f0 */
+#define CWT_PAUL 1   /* psi_ft: mothers.py:118-122, param = m  */
+#define CWT_DOG 2    /* psi_ft: mothers.py:170-173, param = m  */
+
+typedef struct cwt_plan cwt_plan;
+
+/* Library identity: "hip-gfx950" for the product build. */
+const char* cwt_backend(void);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* cwt_last_error(void);
+/* Number of visible GPUs. */
+int cwt_device_count(int* count);
+
+/* ---- plan ---------------------------------------------------------------
+ * One plan per (device, transform length, precision).  nfft is the padded
+ * transform length the reference would use: the next power of two >= len(signal)
+ * (helpers.py:27-30), 2 <= nfft <= 2^24.  max_rows bounds the number of scales
+ * of one cwt_transform_rows call (workspace sizing).                        */
+int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision /* 32 | 64 */,
+                    int max_rows);
+int cwt_plan_destroy(cwt_plan* plan);
+/* hipStream_t handle (as void*) all later launches of this plan are queued on. */
+int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
+/* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  Keys:
+ *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex)
+ *   "narrow"       0 disables the band-limited single-pass path
+ *   "narrow_max_k" largest per-row transform length of that path (power of two)
+ *   "lmax"         largest single-workgroup FFT length (power of two, <= 4096)
+ *   "wg_points"    complex points per workgroup of the fused kernels
+ *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
+int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
+/* Block the host until everything queued by this plan has finished. */
+int cwt_plan_sync(cwt_plan* plan);
+
+/* ---- device memory helpers (so a NumPy-only host needs no other runtime) */
+int cwt_malloc(int device, void** ptr_dev, size_t bytes);
+int cwt_free(int device, void* ptr_dev);
+int cwt_memcpy_h2d(cwt_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
+int cwt_memcpy_d2h(cwt_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- hot path, device resident -----------------------------------------
+ * Forward transform of the real signal, zero padded at the end to nfft:
+ *   xhat[k] = sum_n x[n] exp(-2*pi*i*k*n/nfft)      (unnormalised)
+ * replaces `fft.fft(signal, **fft_kwargs(signal))`, wavelet.py:91.
+ * x_dev: n0 reals; xhat_dev: nfft complex.                                  */
+int cwt_forward_fft(cwt_plan* plan, const void* x_dev, int64_t n0, void* xhat_dev);
+
+/* Rows of the wavelet transform for explicit scales:
+ *   W[j, n] = (1/nfft) sum_k xhat[k] F_j[k] exp(+2*pi*i*k*n/nfft),  n < ncols
+ *   F_j[k]  = sqrt(scales[j]*w_1*nfft) * conj(psi_ft(scales[j]*w_k)),
+ *   w_k     = 2*pi*fftfreq(nfft, dt)[k]
+ * replaces wavelet.py:94 (ftfreqs), :102-104 (psi_ft_bar) and :105-106 (batched
+ * ifft), and the [:, :n0] trim of :123 (ncols = n0).  The filter bank is never
+ * materialised.  For CWT_PAUL the profile is 0 for w <= 0 (the reference yields
+ * NaN rows where exp(-f) overflows, wavelet.py:111-115 then deletes them; the
+ * Python shim deletes the same rows).  W_dev: nrows x ldw complex, row-major.  */
+int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double param, double dt,
+                       const double* scales_host, int nrows, void* W_dev, int64_t ldw,
+                       int64_t ncols);
+
+/* Inverse transform, TC98 eq. 11 (wavelet.py:169-170):
+ *   out[n] = coeff * sum_j Re(W[j, n]) / sqrt(scales[j]),   n < ncols
+ * coeff = dj*sqrt(dt)/(cdelta*psi(0)) is applied by the caller's real part; the
+ * (possibly complex) psi(0) division stays in the shim.  out_dev: ncols reals. */
+int cwt_icwt_reduce(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                    const double* scales_host, double coeff, void* out_dev);
+
+/* ---- host convenience: what the ctypes shim of pycwt.cwt() calls ---------
+ * x_host: n0 reals of the plan's precision.  W_host: nrows x n0 complex (may be
+ * NULL).  xhat_host: nfft complex (may be NULL) for the 5th return value
+ * (wavelet.py:123-124).  Synchronous.                                        */
+int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother, double param,
+                     double dt, const double* scales_host, int nrows, void* W_host,
+                     void* xhat_host);
+
+/* ---- measurement --------------------------------------------------------
+ * With option "profile"=1 every kernel class launched since the last call is
+ * timed with HIP events on the plan's stream.  Fills up to `cap` entries:
+ * names[i] (static strings), total_ms[i], launches[i]; returns the entry count
+ * in *n and resets the accumulators.  Synchronises the stream.              */
+int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_ms,
+                     int* launches, int* n);
+/* How the last cwt_transform_rows call split its rows: counts[0] = rows done by
+ * the single-workgroup kernel, [1] = band-limited single pass, [2] = two-pass. */
+int cwt_plan_last_split(cwt_plan* plan, int counts[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWT_HIP_H */

@@ -1,0 +1,199 @@
+"""ctypes binding of libcwt_hip.so (the C ABI declared in include/cwt_hip.h).
+
+The product opens exactly one library: ``pycwt_amd/libcwt_hip.so``, built for gfx950 by
+``pycwt_amd/_build.py``.  There is no CPU fallback: if the library is missing, cannot be loaded,
+or no GPU is visible, the import / call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "libcwt_hip.so")
+
+MORLET, PAUL, DOG = 0, 1, 2
+
+# every symbol include/cwt_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("cwt_backend", C.c_char_p, []),
+    ("cwt_last_error", C.c_char_p, []),
+    ("cwt_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("cwt_plan_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_int64, C.c_int, C.c_int]),
+    ("cwt_plan_destroy", C.c_int, [_P]),
+    ("cwt_plan_set_stream", C.c_int, [_P, _P]),
+    ("cwt_plan_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("cwt_plan_sync", C.c_int, [_P]),
+    ("cwt_malloc", C.c_int, [C.c_int, C.POINTER(_P), C.c_size_t]),
+    ("cwt_free", C.c_int, [C.c_int, _P]),
+    ("cwt_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("cwt_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
+    ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                     C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_icwt_reduce", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double),
+                                  C.c_double, _P]),
+    ("cwt_execute_host", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
+                                   C.POINTER(C.c_double), C.c_int, _P, _P]),
+    ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
+]
+
+
+class HipError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class Library:
+    """A loaded libcwt_hip.so with typed entry points."""
+
+    def __init__(self, path: str = DEFAULT_LIBRARY):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m pycwt_amd._build). "
+                "pycwt_amd has no CPU fallback.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(self.dll, name)      # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+
+    def backend(self) -> str:
+        return self.cwt_backend().decode()
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise HipError(f"libcwt_hip error {rc}: {self.cwt_last_error().decode()}")
+
+    def device_count(self) -> int:
+        n = C.c_int(0)
+        self.check(self.cwt_device_count(C.byref(n)))
+        return n.value
+
+
+_default = None
+
+
+def load() -> Library:
+    """The product library (HIP, gfx950).  Raises if it is missing."""
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_LIBRARY)
+    return _default
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Plan:
+    """One (device, nfft, precision) plan; thin RAII wrapper over the C ABI."""
+
+    def __init__(self, nfft: int, precision: int = 64, max_rows: int = 1024, device: int = 0,
+                 lib: Library | None = None, options: dict | None = None):
+        self.lib = lib or load()
+        self.nfft = int(nfft)
+        self.precision = int(precision)
+        self.device = device
+        self.max_rows = int(max_rows)
+        self.real = np.float64 if precision == 64 else np.float32
+        self.cplx = np.complex128 if precision == 64 else np.complex64
+        h = _P()
+        self.lib.check(self.lib.cwt_plan_create(C.byref(h), device, self.nfft, self.precision, self.max_rows))
+        self.h = h
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cwt_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_option(self, key: str, value: int):
+        self.lib.check(self.lib.cwt_plan_set_option(self.h, key.encode(), int(value)))
+
+    def set_stream(self, stream_handle: int):
+        self.lib.check(self.lib.cwt_plan_set_stream(self.h, _P(stream_handle)))
+
+    def sync(self):
+        self.lib.check(self.lib.cwt_plan_sync(self.h))
+
+    # -- device-resident entry points (raw device addresses as ints) --
+    def forward_fft(self, x_dev: int, n0: int, xhat_dev: int):
+        self.lib.check(self.lib.cwt_forward_fft(self.h, _P(x_dev), n0, _P(xhat_dev)))
+
+    def transform_rows(self, xhat_dev: int, mother: int, param: float, dt: float, scales, W_dev: int,
+                       ldw: int, ncols: int):
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
+                                                   _dptr(s), s.size, _P(W_dev), ldw, ncols))
+
+    def icwt_reduce(self, W_dev: int, ldw: int, ncols: int, scales, coeff: float, out_dev: int):
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_icwt_reduce(self.h, _P(W_dev), ldw, ncols, s.size, _dptr(s),
+                                                float(coeff), _P(out_dev)))
+
+    # -- host convenience --
+    def execute_host(self, x, mother: int, param: float, dt: float, scales, want_W=True, want_xhat=True):
+        x = np.ascontiguousarray(x, dtype=self.real)
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        n0 = x.size
+        W = np.empty((s.size, n0), dtype=self.cplx) if want_W else None
+        xhat = np.empty(self.nfft, dtype=self.cplx) if want_xhat else None
+        self.lib.check(self.lib.cwt_execute_host(
+            self.h, x.ctypes.data_as(_P), n0, mother, float(param), float(dt), _dptr(s), s.size,
+            W.ctypes.data_as(_P) if want_W else None, xhat.ctypes.data_as(_P) if want_xhat else None))
+        return W, xhat
+
+    def timings(self):
+        cap = 16
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int * cap)()
+        n = C.c_int(0)
+        self.lib.check(self.lib.cwt_plan_timings(self.h, cap, names, ms, cnt, C.byref(n)))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n.value, cap))}
+
+    def last_split(self):
+        c = (C.c_int * 3)()
+        self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
+        return {"small": c[0], "narrow": c[1], "two_pass": c[2]}
+
+
+class DeviceBuffer:
+    """Device memory owned through cwt_malloc / cwt_free (used by the NumPy-only host path)."""
+
+    def __init__(self, nbytes: int, device: int = 0, lib: Library | None = None):
+        self.lib = lib or load()
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = _P()
+        self.lib.check(self.lib.cwt_malloc(device, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.cwt_free(self.device, _P(self.ptr))
+            self.ptr = None
+
+    __del__ = free
+
+    def upload(self, plan: Plan, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.lib.check(self.lib.cwt_memcpy_h2d(plan.h, _P(self.ptr), arr.ctypes.data_as(_P), arr.nbytes))
+
+    def download(self, plan: Plan, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.lib.check(self.lib.cwt_memcpy_d2h(plan.h, out.ctypes.data_as(_P), _P(self.ptr), out.nbytes))
+        return out

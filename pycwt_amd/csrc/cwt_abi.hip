@@ -1,0 +1,661 @@
+// cwt_abi.hip -- host side of libcwt_hip.so: plan, row classification, launches, C ABI.
+// See include/cwt_hip.h for the contract and the reference lines each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cwt_hip.h"
+#include "cwt_kernels.hpp"
+
+#ifndef CWT_BACKEND_NAME
+#define CWT_BACKEND_NAME "hip-gfx950"
+#endif
+
+using namespace cwt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHECK(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(CWT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+
+enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_PASS_A,
+                   KC_PASS_B, KC_ICWT, KC_COUNT };
+const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a", "fwd_pass_b", "small", "direct",
+                                           "narrow",    "pass_a",     "pass_b",     "icwt"};
+
+int ilog2(int64_t v) {
+  int l = 0;
+  while ((int64_t(1) << l) < v) ++l;
+  return l;
+}
+
+struct Timed { int cls; hipEvent_t a, b; };
+
+}  // namespace
+
+struct cwt_plan {
+  int device = 0;
+  int logN = 0;
+  int64_t N = 0;
+  int prec = 64;
+  int max_rows = 0;
+  hipStream_t stream = nullptr;
+  // options
+  int chunk_rows = 4;
+  int narrow = 1;
+  int narrow_max_logk = 10;
+  int loglmax = 12;
+  int log_wg_points = 13;
+  int profile = 0;
+  // device resources
+  void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
+  void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
+  int twn_shift = 0;
+  RowDesc* rows_dev = nullptr;
+  RowDesc* rows_pinned = nullptr;
+  void* weights_dev = nullptr;
+  void* weights_pinned = nullptr;
+  void* Z = nullptr;
+  size_t z_bytes = 0;
+  // buffers of cwt_execute_host
+  void* hx = nullptr; size_t hx_bytes = 0;
+  void* hxhat = nullptr; size_t hxhat_bytes = 0;
+  void* hW = nullptr; size_t hW_bytes = 0;
+  // cache of the last row table (skip re-upload when the call repeats)
+  std::vector<double> last_scales;
+  int last_mother = -1; double last_param = 0, last_dt = 0;
+  bool table_valid = false;
+  std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
+  struct Group { int logK; int first; int count; };
+  std::vector<Group> narrow_groups;
+  int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
+  int split[3] = {0, 0, 0};
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> free_events;
+
+  size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
+};
+
+namespace {
+
+template <typename T>
+const cplx<T>* tw_table(const cwt_plan* p, int logL) {
+  return static_cast<const cplx<T>*>(p->tw_all) + ((size_t(1) << logL) - 2);
+}
+
+template <typename T>
+TwN<T> twn_of(const cwt_plan* p) {
+  TwN<T> t;
+  t.shift = p->twn_shift;
+  t.lo = static_cast<const cplx<T>*>(p->twn_lo);
+  t.hi = tw_table<T>(p, p->logN - p->twn_shift);
+  return t;
+}
+
+int get_event(cwt_plan* p, hipEvent_t* e) {
+  if (!p->free_events.empty()) {
+    *e = p->free_events.back();
+    p->free_events.pop_back();
+    return CWT_OK;
+  }
+  HIPCHECK(hipEventCreate(e));
+  return CWT_OK;
+}
+
+// Runs `launch()` (which enqueues exactly one kernel class) and, when profiling, brackets it with
+// HIP events on the plan's stream.
+template <class F>
+int timed_launch(cwt_plan* p, int cls, F&& launch) {
+  if (!p->profile) {
+    launch();
+    HIPCHECK(hipGetLastError());
+    return CWT_OK;
+  }
+  Timed t;
+  t.cls = cls;
+  int rc = get_event(p, &t.a);
+  if (rc) return rc;
+  rc = get_event(p, &t.b);
+  if (rc) return rc;
+  HIPCHECK(hipEventRecord(t.a, p->stream));
+  launch();
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(t.b, p->stream));
+  p->timed.push_back(t);
+  return CWT_OK;
+}
+
+template <typename T>
+int build_tables(cwt_plan* p) {
+  const long double two_pi = 6.283185307179586476925286766559L;
+  std::vector<cplx<T>> all(8190);
+  for (int l = 1; l <= 12; ++l) {
+    const size_t L = size_t(1) << l;
+    for (size_t i = 0; i < L; ++i) {
+      const long double ang = two_pi * (long double)i / (long double)L;
+      all[L - 2 + i] = mk<T>(T(cosl(ang)), T(sinl(ang)));
+    }
+  }
+  HIPCHECK(hipMalloc(&p->tw_all, all.size() * sizeof(cplx<T>)));
+  HIPCHECK(hipMemcpy(p->tw_all, all.data(), all.size() * sizeof(cplx<T>), hipMemcpyHostToDevice));
+  p->twn_shift = p->logN / 2;
+  if (p->logN - p->twn_shift > 12) p->twn_shift = p->logN - 12;
+  const size_t nlo = size_t(1) << p->twn_shift;
+  std::vector<cplx<T>> lo(nlo);
+  for (size_t i = 0; i < nlo; ++i) {
+    const long double ang = two_pi * (long double)i / (long double)p->N;
+    lo[i] = mk<T>(T(cosl(ang)), T(sinl(ang)));
+  }
+  HIPCHECK(hipMalloc(&p->twn_lo, nlo * sizeof(cplx<T>)));
+  HIPCHECK(hipMemcpy(p->twn_lo, lo.data(), nlo * sizeof(cplx<T>), hipMemcpyHostToDevice));
+  return CWT_OK;
+}
+
+// ---- filter support (band) of one row ------------------------------------------------------
+// Bins whose profile is below eps * (peak of the profile) are treated as exactly zero; eps is far
+// below the arithmetic's own rounding (1e-18 for fp64, 1e-9 for fp32).
+double solve_decreasing(double lo, double target, double (*h)(double, double), double m) {
+  // find f > lo with h(f, m) = target, h decreasing beyond lo
+  double hi = lo + 1.0;
+  while (h(hi, m) > target) hi = lo + 2.0 * (hi - lo);
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (h(mid, m) > target) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+double h_paul(double f, double m) { return (m > 0 ? m * std::log(f) : 0.0) - f; }
+double h_dog(double f, double m) { return (m > 0 ? m * std::log(f) : 0.0) - 0.5 * f * f; }
+
+void profile_support(int mother, double p, double eps, double* f_lo, double* f_hi) {
+  const double le = std::log(eps);
+  if (mother == MOTHER_MORLET) {
+    const double xc = std::sqrt(-2.0 * le);
+    *f_lo = p - xc;
+    *f_hi = p + xc;
+  } else if (mother == MOTHER_PAUL) {
+    const double peak = p > 0 ? h_paul(p, p) : 0.0;
+    *f_lo = 0.0;
+    *f_hi = solve_decreasing(p > 0 ? p : 0.0, peak + le, h_paul, p);
+  } else {
+    const double fp = std::sqrt(p > 0 ? p : 0.0);
+    const double peak = p > 0 ? h_dog(fp, p) : 0.0;
+    *f_hi = solve_decreasing(fp, peak + le, h_dog, p);
+    *f_lo = -*f_hi;
+  }
+}
+
+int build_row_table(cwt_plan* p, int mother, double param, double dt, const double* scales,
+                    int nrows) {
+  const double pi = 3.14159265358979323846;
+  const int64_t N = p->N;
+  const double w1 = 2.0 * pi * (1.0 / (double(N) * dt));  // ftfreqs[1], wavelet.py:94
+  const int m = int(std::lround(param));
+  double cre = 1.0, cim = 0.0;
+  if (mother == MOTHER_MORLET) {
+    cre = std::pow(pi, -0.25);
+  } else if (mother == MOTHER_PAUL) {
+    if (m < 1 || double(m) != param) return fail(CWT_EINVAL, "Paul order m must be an integer >= 1");
+    cre = std::pow(2.0, m) / std::sqrt(double(m) * std::tgamma(2.0 * m));  // (2m-1)! = Gamma(2m)
+  } else if (mother == MOTHER_DOG) {
+    if (m < 0 || double(m) != param) return fail(CWT_EINVAL, "DOG order m must be an integer >= 0");
+    const double g = 1.0 / std::sqrt(std::tgamma(m + 0.5));
+    // conj(-(i^m)): m%4 = 0 -> -1, 1 -> +i, 2 -> +1, 3 -> -i
+    const double tr[4] = {-1, 0, 1, 0}, ti[4] = {0, 1, 0, -1};
+    cre = tr[m & 3] * g;
+    cim = ti[m & 3] * g;
+  } else {
+    return fail(CWT_EINVAL, "unknown mother id");
+  }
+  double f_lo, f_hi;
+  profile_support(mother, param, p->prec == 64 ? 1e-18 : 1e-9, &f_lo, &f_hi);
+
+  const int logP = std::min(p->log_wg_points, p->logN);
+  const bool use_small = p->logN <= p->loglmax;
+  const int narrow_cap = std::min(p->narrow_max_logk, logP - 1);
+  std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
+  for (int j = 0; j < nrows; ++j) {
+    const double s = scales[j];
+    if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
+    RowDesc rd;
+    rd.a = s * w1;
+    const double norm = std::sqrt(s * w1 * double(N)) / double(N);
+    rd.amp_re = norm * cre;
+    rd.amp_im = norm * cim;
+    double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
+    if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
+    klo = std::max(klo, -double(N / 2));
+    khi = std::min(khi, double(N / 2 - 1));
+    if (N == 1) { klo = 0; khi = 0; }
+    rd.k_lo = int(klo);
+    rd.nband = khi >= klo ? int(khi - klo + 1) : 0;
+    if (rd.nband == 0) rd.k_lo = 0;
+    rd.out_row = j;
+    rd.logK = 0;
+    if (use_small) {
+      small_rows.push_back(rd);
+    } else {
+      const int need = std::max(4, ilog2(std::max(rd.nband, 1)));
+      if (p->narrow && need <= narrow_cap) {
+        rd.logK = need;
+        narrow_rows.push_back(rd);
+      } else {
+        wide_rows.push_back(rd);
+      }
+    }
+  }
+  std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
+                   [](const RowDesc& x, const RowDesc& y) { return x.logK < y.logK; });
+  p->table.clear();
+  p->narrow_groups.clear();
+  p->table.insert(p->table.end(), small_rows.begin(), small_rows.end());
+  for (size_t i = 0; i < narrow_rows.size(); ++i) {
+    if (p->narrow_groups.empty() || p->narrow_groups.back().logK != narrow_rows[i].logK)
+      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0});
+    p->narrow_groups.back().count++;
+    p->table.push_back(narrow_rows[i]);
+  }
+  p->wide_first = int(p->table.size());
+  p->table.insert(p->table.end(), wide_rows.begin(), wide_rows.end());
+  p->n_small = int(small_rows.size());
+  p->n_narrow = int(narrow_rows.size());
+  p->n_wide = int(wide_rows.size());
+  return CWT_OK;
+}
+
+// log2 of the row length K of the two-pass factorisation N = R*K
+int two_pass_logk(const cwt_plan* p) {
+  int lk = std::min(10, p->logN - 4);
+  lk = std::max(lk, p->logN - p->loglmax);
+  lk = std::min(lk, p->loglmax);
+  return lk;
+}
+
+int ensure_z(cwt_plan* p, int rows) {
+  const size_t need = size_t(rows) * size_t(p->N) * 2 * p->esize();
+  if (p->z_bytes >= need) return CWT_OK;
+  if (p->Z) { HIPCHECK(hipStreamSynchronize(p->stream)); HIPCHECK(hipFree(p->Z)); p->Z = nullptr; p->z_bytes = 0; }
+  if (hipMalloc(&p->Z, need) != hipSuccess) return fail(CWT_ENOMEM, "cannot allocate two-pass workspace");
+  p->z_bytes = need;
+  return CWT_OK;
+}
+
+template <typename T>
+int forward_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
+  const int logN = p->logN;
+  const Mother mo{MOTHER_MORLET, 0, 0.0};
+  cplx<T>* out = static_cast<cplx<T>*>(xhat_dev);
+  if (logN <= 3) {
+    return timed_launch(p, KC_FWD_SMALL, [&] {
+      hipLaunchKernelGGL((k_direct<T, IN_REAL>), dim3(1), dim3(64), 0, p->stream, x_dev,
+                         (const RowDesc*)nullptr, 1, mo, logN, long(n0), out, long(p->N), long(p->N));
+    });
+  }
+  if (logN <= p->loglmax) {
+    const int threads = 1 << (logN - 4);
+    const size_t lds = (size_t(1) << logN) * sizeof(T);
+    return timed_launch(p, KC_FWD_SMALL, [&] {
+      hipLaunchKernelGGL((k_small<T, IN_REAL>), dim3(1), dim3(threads), lds, p->stream, x_dev,
+                         (const RowDesc*)nullptr, 1, mo, tw_table<T>(p, logN), logN, 0, long(n0), out,
+                         long(p->N), long(p->N));
+    });
+  }
+  const int logK = two_pass_logk(p), logR = logN - logK;
+  const int logP = std::min(p->log_wg_points, logN);
+  int rc = ensure_z(p, 1);
+  if (rc) return rc;
+  const size_t lds = (size_t(1) << logP) * sizeof(T);
+  const int threads = 1 << (logP - 4);
+  rc = timed_launch(p, KC_FWD_A, [&] {
+    hipLaunchKernelGGL((k_pass_a<T, IN_REAL>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
+                       x_dev, (const RowDesc*)nullptr, mo, tw_table<T>(p, logR), twn_of<T>(p), logN,
+                       logK, logP - logR, long(n0), static_cast<cplx<T>*>(p->Z));
+  });
+  if (rc) return rc;
+  return timed_launch(p, KC_FWD_B, [&] {
+    hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
+                       static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
+                       logN, logK, logP - logK, out, long(p->N), long(p->N));
+  });
+}
+
+template <typename T>
+int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, void* W_dev, int64_t ldw,
+              int64_t ncols) {
+  const int logN = p->logN;
+  const cplx<T>* xhat = static_cast<const cplx<T>*>(xhat_dev);
+  cplx<T>* W = static_cast<cplx<T>*>(W_dev);
+  int rc;
+  if (p->n_small) {
+    if (logN <= 3) {
+      const int total = nrows << logN;
+      return timed_launch(p, KC_DIRECT, [&] {
+        hipLaunchKernelGGL((k_direct<T, IN_SPECTRUM>), dim3((total + 63) / 64), dim3(64), 0, p->stream,
+                           xhat_dev, p->rows_dev, nrows, mo, logN, 0L, W, long(ldw), long(ncols));
+      });
+    }
+    // several rows per workgroup: aim at 4096 points (256 threads)
+    const int logTB = std::max(0, std::min(12, p->log_wg_points) - logN);
+    const int TB = 1 << logTB;
+    const int threads = TB << (logN - 4);
+    const size_t lds = (size_t(TB) << logN) * sizeof(T);
+    return timed_launch(p, KC_SMALL, [&] {
+      hipLaunchKernelGGL((k_small<T, IN_SPECTRUM>), dim3((nrows + TB - 1) / TB), dim3(threads), lds,
+                         p->stream, xhat_dev, p->rows_dev, nrows, mo, tw_table<T>(p, logN), logN, logTB,
+                         0L, W, long(ldw), long(ncols));
+    });
+  }
+  const int logP = std::min(p->log_wg_points, logN);
+  const int threads = 1 << (logP - 4);
+  const size_t lds = (size_t(1) << logP) * sizeof(T);
+  for (const auto& g : p->narrow_groups) {
+    rc = timed_launch(p, KC_NARROW, [&] {
+      hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
+                         xhat, p->rows_dev + g.first, mo, tw_table<T>(p, g.logK), twn_of<T>(p), logN,
+                         g.logK, logP - g.logK, W, long(ldw), long(ncols));
+    });
+    if (rc) return rc;
+  }
+  if (p->n_wide) {
+    const int logK = two_pass_logk(p), logR = logN - logK;
+    const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));
+    rc = ensure_z(p, chunk);
+    if (rc) return rc;
+    for (int first = 0; first < p->n_wide; first += chunk) {
+      const int cnt = std::min(chunk, p->n_wide - first);
+      const RowDesc* rows = p->rows_dev + p->wide_first + first;
+      rc = timed_launch(p, KC_PASS_A, [&] {
+        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
+                           p->stream, xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK,
+                           logP - logR, 0L, static_cast<cplx<T>*>(p->Z));
+      });
+      if (rc) return rc;
+      rc = timed_launch(p, KC_PASS_B, [&] {
+        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
+                           p->stream, static_cast<const cplx<T>*>(p->Z), rows, tw_table<T>(p, logK), logN,
+                           logK, logP - logK, W, long(ldw), long(ncols));
+      });
+      if (rc) return rc;
+    }
+  }
+  return CWT_OK;
+}
+
+template <typename T>
+int set_func_attrs() {
+  const int big = 160 * 1024;
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small<T, IN_REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small<T, IN_SPECTRUM>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_narrow<T>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass_a<T, IN_REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass_a<T, IN_SPECTRUM>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass_b<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass_b<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  return CWT_OK;
+}
+
+int grow(void** buf, size_t* have, size_t need, hipStream_t s) {
+  if (*have >= need) return CWT_OK;
+  if (*buf) { HIPCHECK(hipStreamSynchronize(s)); HIPCHECK(hipFree(*buf)); *buf = nullptr; *have = 0; }
+  if (hipMalloc(buf, need) != hipSuccess) return fail(CWT_ENOMEM, "device allocation failed");
+  *have = need;
+  return CWT_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* cwt_backend(void) { return CWT_BACKEND_NAME; }
+const char* cwt_last_error(void) { return g_err.c_str(); }
+
+int cwt_device_count(int* count) {
+  if (!count) return fail(CWT_EINVAL, "count is NULL");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; return fail(CWT_ENODEV, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  return CWT_OK;
+}
+
+int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, int max_rows) {
+  if (!plan) return fail(CWT_EINVAL, "plan is NULL");
+  *plan = nullptr;
+  if (precision != 32 && precision != 64) return fail(CWT_EINVAL, "precision must be 32 or 64");
+  if (nfft < 2 || nfft > (int64_t(1) << 24) || (nfft & (nfft - 1)))
+    return fail(CWT_EINVAL, "nfft must be a power of two in [2, 2^24]");
+  if (max_rows < 1) return fail(CWT_EINVAL, "max_rows must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CWT_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(CWT_EINVAL, "device index out of range");
+  HIPCHECK(hipSetDevice(device));
+  cwt_plan* p = new cwt_plan();
+  p->device = device;
+  p->N = nfft;
+  p->logN = ilog2(nfft);
+  p->prec = precision;
+  p->max_rows = max_rows;
+  int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
+  if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
+  if (!rc && hipMalloc(reinterpret_cast<void**>(&p->rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+    rc = fail(CWT_ENOMEM, "row table allocation failed");
+  if (!rc && hipMalloc(&p->weights_dev, size_t(max_rows) * sizeof(double)) != hipSuccess)
+    rc = fail(CWT_ENOMEM, "weights allocation failed");
+  if (!rc && hipHostMalloc(reinterpret_cast<void**>(&p->rows_pinned), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+    rc = fail(CWT_ENOMEM, "pinned row table allocation failed");
+  if (!rc && hipHostMalloc(&p->weights_pinned, size_t(max_rows) * sizeof(double)) != hipSuccess)
+    rc = fail(CWT_ENOMEM, "pinned weights allocation failed");
+  if (rc) { cwt_plan_destroy(p); return rc; }
+  *plan = p;
+  return CWT_OK;
+}
+
+int cwt_plan_destroy(cwt_plan* p) {
+  if (!p) return CWT_OK;
+  hipSetDevice(p->device);
+  hipStreamSynchronize(p->stream);
+  for (auto& t : p->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  for (auto e : p->free_events) hipEventDestroy(e);
+  void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW};
+  for (void* b : bufs) if (b) hipFree(b);
+  if (p->rows_pinned) hipHostFree(p->rows_pinned);
+  if (p->weights_pinned) hipHostFree(p->weights_pinned);
+  delete p;
+  return CWT_OK;
+}
+
+int cwt_plan_set_stream(cwt_plan* p, void* hip_stream) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  p->stream = static_cast<hipStream_t>(hip_stream);
+  return CWT_OK;
+}
+
+int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return fail(CWT_EINVAL, "plan/key is NULL");
+  const std::string k(key);
+  auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
+  p->table_valid = false;
+  if (k == "chunk_rows") { if (value < 1) return fail(CWT_EINVAL, "chunk_rows >= 1"); p->chunk_rows = int(value); }
+  else if (k == "narrow") p->narrow = value != 0;
+  else if (k == "narrow_max_k") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "narrow_max_k: power of two in [16,4096]"); p->narrow_max_logk = ilog2(value); }
+  else if (k == "lmax") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "lmax: power of two in [16,4096]"); p->loglmax = ilog2(value); }
+  else if (k == "wg_points") { if (!pow2(value) || value < 256 || value > 16384) return fail(CWT_EINVAL, "wg_points: power of two in [256,16384]"); p->log_wg_points = ilog2(value); }
+  else if (k == "profile") p->profile = value != 0;
+  else return fail(CWT_EINVAL, "unknown option " + k);
+  if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
+  return CWT_OK;
+}
+
+int cwt_plan_sync(cwt_plan* p) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  return CWT_OK;
+}
+
+int cwt_malloc(int device, void** ptr, size_t bytes) {
+  if (!ptr) return fail(CWT_EINVAL, "ptr is NULL");
+  HIPCHECK(hipSetDevice(device));
+  if (hipMalloc(ptr, bytes) != hipSuccess) return fail(CWT_ENOMEM, "hipMalloc failed");
+  return CWT_OK;
+}
+int cwt_free(int device, void* ptr) {
+  HIPCHECK(hipSetDevice(device));
+  HIPCHECK(hipFree(ptr));
+  return CWT_OK;
+}
+int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  return CWT_OK;
+}
+int cwt_memcpy_d2h(cwt_plan* p, void* dst, const void* src, size_t bytes) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  return CWT_OK;
+}
+
+int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
+  if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? forward_impl<double>(p, x_dev, n0, xhat_dev)
+                       : forward_impl<float>(p, x_dev, n0, xhat_dev);
+}
+
+int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double param, double dt,
+                       const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
+  if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
+  if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
+  if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
+  HIPCHECK(hipSetDevice(p->device));
+  const bool same = p->table_valid && p->last_mother == mother && p->last_param == param &&
+                    p->last_dt == dt && int(p->last_scales.size()) == nrows &&
+                    std::equal(scales, scales + nrows, p->last_scales.begin());
+  if (!same) {
+    p->table_valid = false;
+    int rc = build_row_table(p, mother, param, dt, scales, nrows);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(p->stream));  // the pinned staging buffer may still be in flight
+    std::memcpy(p->rows_pinned, p->table.data(), p->table.size() * sizeof(RowDesc));
+    HIPCHECK(hipMemcpyAsync(p->rows_dev, p->rows_pinned, p->table.size() * sizeof(RowDesc),
+                            hipMemcpyHostToDevice, p->stream));
+    p->last_mother = mother; p->last_param = param; p->last_dt = dt;
+    p->last_scales.assign(scales, scales + nrows);
+    p->table_valid = true;
+  }
+  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  Mother mo;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param;
+  return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
+                       : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
+}
+
+int cwt_icwt_reduce(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                    const double* scales, double coeff, void* out_dev) {
+  if (!p || !W_dev || !scales || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
+  if (ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "need ncols >= 1 and ldw >= ncols");
+  HIPCHECK(hipSetDevice(p->device));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  for (int j = 0; j < nrows; ++j) {
+    if (!(scales[j] > 0)) return fail(CWT_EINVAL, "scales must be positive");
+    const double w = 1.0 / std::sqrt(scales[j]);
+    if (p->prec == 64) static_cast<double*>(p->weights_pinned)[j] = w;
+    else static_cast<float*>(p->weights_pinned)[j] = float(w);
+  }
+  HIPCHECK(hipMemcpyAsync(p->weights_dev, p->weights_pinned, size_t(nrows) * p->esize(),
+                          hipMemcpyHostToDevice, p->stream));
+  const unsigned blocks = unsigned((ncols + 255) / 256);
+  if (p->prec == 64)
+    return timed_launch(p, KC_ICWT, [&] {
+      hipLaunchKernelGGL((k_icwt<double>), dim3(blocks), dim3(256), 0, p->stream,
+                         static_cast<const double2*>(W_dev), long(ldw), long(ncols), nrows,
+                         static_cast<const double*>(p->weights_dev), coeff, static_cast<double*>(out_dev));
+    });
+  return timed_launch(p, KC_ICWT, [&] {
+    hipLaunchKernelGGL((k_icwt<float>), dim3(blocks), dim3(256), 0, p->stream,
+                       static_cast<const float2*>(W_dev), long(ldw), long(ncols), nrows,
+                       static_cast<const float*>(p->weights_dev), float(coeff), static_cast<float*>(out_dev));
+  });
+}
+
+int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, double param, double dt,
+                     const double* scales, int nrows, void* W_host, void* xhat_host) {
+  if (!p || !x_host || !scales) return fail(CWT_EINVAL, "NULL argument");
+  if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
+  HIPCHECK(hipSetDevice(p->device));
+  const size_t es = p->esize();
+  int rc = grow(&p->hx, &p->hx_bytes, size_t(n0) * es, p->stream);
+  if (!rc) rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * 2 * es, p->stream);
+  if (!rc && W_host) rc = grow(&p->hW, &p->hW_bytes, size_t(nrows) * size_t(n0) * 2 * es, p->stream);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(p->hx, x_host, size_t(n0) * es, hipMemcpyHostToDevice, p->stream));
+  rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
+  if (rc) return rc;
+  if (W_host) {
+    rc = cwt_transform_rows(p, p->hxhat, mother, param, dt, scales, nrows, p->hW, n0, n0);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(W_host, p->hW, size_t(nrows) * size_t(n0) * 2 * es, hipMemcpyDeviceToHost, p->stream));
+  }
+  if (xhat_host)
+    HIPCHECK(hipMemcpyAsync(xhat_host, p->hxhat, size_t(p->N) * 2 * es, hipMemcpyDeviceToHost, p->stream));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  return CWT_OK;
+}
+
+int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms, int* launches, int* n) {
+  if (!p || !n) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  double tot[KC_COUNT] = {0};
+  int cnt[KC_COUNT] = {0};
+  for (auto& t : p->timed) {
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, t.a, t.b));
+    tot[t.cls] += ms;
+    cnt[t.cls]++;
+    p->free_events.push_back(t.a);
+    p->free_events.push_back(t.b);
+  }
+  p->timed.clear();
+  int k = 0;
+  for (int c = 0; c < KC_COUNT; ++c) {
+    if (!cnt[c]) continue;
+    if (k < cap) {
+      if (names) names[k] = kClassNames[c];
+      if (total_ms) total_ms[k] = tot[c];
+      if (launches) launches[k] = cnt[c];
+    }
+    ++k;
+  }
+  *n = k;
+  return CWT_OK;
+}
+
+int cwt_plan_last_split(cwt_plan* p, int counts[3]) {
+  if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
+  counts[0] = p->split[0]; counts[1] = p->split[1]; counts[2] = p->split[2];
+  return CWT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// cwt_kernels.hpp -- the HIP kernels of the CWT hot path (gfx950).
+//
+// Math (pycwt/wavelet.py:91-106): W[j, n] = (1/N) sum_k xhat[k] F_j[k] e^{+2 pi i k n / N},
+// F_j[k] = sqrt(2 pi s_j / dt) conj(psi_ft(s_j w_k)).  F_j is never stored: every kernel that
+// consumes the spectrum evaluates profile(s_j w_k) on the fly and multiplies by a per-row
+// complex amplitude that carries the norm, the mother's constant and the 1/N of the inverse FFT.
+//
+// Kernels (T = float | double):
+//   k_small   N <= lmax            one workgroup FFT per row (also the forward FFT of the signal)
+//   k_direct  N <= 8               plain DFT (sizes below the radix-16 engine)
+//   k_narrow  band-limited rows    single pass: aliased K_j-point FFTs, N = K_j * R_j
+//   k_pass_a  wide rows, pass 1    column FFTs over k1 (k = q + K k1) + twiddle e^{2 pi i q r / N}
+//   k_pass_b  wide rows, pass 2    row FFTs over q, LDS transpose, store W[R m + r]
+//   k_icwt    TC98 eq. 11 column reduction (wavelet.py:169-170)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_engine.hpp"
+
+#ifndef CWT_MAX_THREADS
+#define CWT_MAX_THREADS 1024
+#endif
+namespace cwt {
+
+enum : int { MOTHER_MORLET = 0, MOTHER_PAUL = 1, MOTHER_DOG = 2 };
+enum : int { IN_SPECTRUM = 0, IN_REAL = 1 };
+
+// One row (scale) of the transform, prepared on the host in double precision.
+struct RowDesc {
+  double a;        // s_j * 2 pi / (N dt): profile argument = a * signed bin index
+  double amp_re;   // complex amplitude: sqrt(s w_1 N) * mother constant / N  (conj applied)
+  double amp_im;
+  int k_lo;        // first signed bin index of the filter's support, >= -N/2
+  int nband;       // number of bins in the support; k_lo + nband - 1 <= N/2 - 1
+  int out_row;     // destination row of W
+  int logK;        // k_narrow: log2 of this row's FFT length
+};
+
+struct Mother {
+  int kind;    // MOTHER_*
+  int m;       // integer order for Paul / DOG
+  double p;    // f0 (Morlet) or m
+};
+
+// Tables for e^{2 pi i t / N}, t < N, as a product of a coarse and a fine root of unity.
+template <typename T>
+struct TwN {
+  const cplx<T>* hi;  // hi[i] = e^{2 pi i (i << shift) / N}
+  const cplx<T>* lo;  // lo[i] = e^{2 pi i i / N}, i < (1 << shift)
+  int shift;
+  __device__ __forceinline__ cplx<T> operator()(unsigned t) const {
+    return cmul<T>(hi[t >> shift], lo[t & ((1u << shift) - 1u)]);
+  }
+};
+
+__device__ __forceinline__ double exp_(double x) { return exp(x); }
+__device__ __forceinline__ float exp_(float x) { return expf(x); }
+
+template <typename T>
+__device__ __forceinline__ T ipow(T b, int e) {
+  T r = T(1);
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
+}
+
+// Real profile of psi_ft at f = s*w (mothers.py:26-28, 118-122, 170-173) without the mother's
+// constant factor; Paul is 0 for f <= 0 (the mathematically intended value, see cwt_hip.h).
+template <typename T>
+__device__ __forceinline__ T profile(const Mother& mo, T f) {
+  if (mo.kind == MOTHER_MORLET) {
+    const T d = f - T(mo.p);
+    return exp_(T(-0.5) * d * d);
+  }
+  const T pw = ipow<T>(f, mo.m);
+  if (mo.kind == MOTHER_PAUL) return f > T(0) ? pw * exp_(-f) : T(0);
+  return pw * exp_(T(-0.5) * f * f);
+}
+
+// xhat[k] * F_row[k] for signed bin ks (0 outside the row's band).
+template <typename T>
+__device__ __forceinline__ cplx<T> filtered_bin(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
+                                                const Mother& mo, int ks, int nmask) {
+  const unsigned d = unsigned(ks - rd.k_lo);
+  if (d >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
+  const T g = profile<T>(mo, T(rd.a) * T(ks));
+  const cplx<T> x = xhat[ks & nmask];
+  const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
+  return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
+}
+
+__device__ __forceinline__ int signed_bin(int k, int N) { return k < (N >> 1) ? k : k - N; }
+
+// ---------------------------------------------------------------------------------------------
+// k_small: whole transform of length N = 2^logN (16..lmax) inside one workgroup, TB rows per WG.
+// MODE IN_SPECTRUM: rows of W.  MODE IN_REAL: forward FFT of the zero-padded real signal
+// (nrows = 1, out = conj(inverse(x))).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(CWT_MAX_THREADS)
+k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows, Mother mo,
+        const cplx<T>* __restrict__ tw, int logN, int logTB, long n0, cplx<T>* __restrict__ out,
+        long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const int N = 1 << logN, logNT = logN - 4, NT = 1 << logNT;
+  Geo<T, false> g;
+  g.logL = logN; g.logTB = logTB;
+  g.j = threadIdx.x & (NT - 1);
+  g.t = threadIdx.x >> logNT;
+  const int row = blockIdx.x * (1 << logTB) + g.t;
+  const bool live = row < nrows;
+  T re[16], im[16];
+  if constexpr (MODE == IN_REAL) {
+    const T* x = static_cast<const T*>(in);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = g.j + (e << logNT);
+      re[e] = (live && k < n0) ? x[k] : T(0);
+      im[e] = T(0);
+    }
+  } else {
+    const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
+    RowDesc rd;
+    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = g.j + (e << logNT);
+      const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
+      re[e] = v.x; im[e] = v.y;
+    }
+  }
+  wg_ifft<T, false>(re, im, lds, g, tw);
+  if (!live) return;
+  const long orow = (MODE == IN_REAL) ? 0 : long(rows[row].out_row);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long m = g.j + (e << logNT);
+    if (m < ncols) out[orow * ldw + m] = mk<T>(re[e], MODE == IN_REAL ? -im[e] : im[e]);
+  }
+}
+
+// k_direct: N <= 8.  One thread per output element.
+template <typename T, int MODE>
+__global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows,
+                         Mother mo, int logN, long n0, cplx<T>* __restrict__ out, long ldw,
+                         long ncols) {
+  const int N = 1 << logN;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = idx >> logN, m = idx & (N - 1);
+  if (row >= nrows || m >= ncols) return;
+  double sr = 0, si = 0;
+  for (int k = 0; k < N; ++k) {
+    double yr, yi;
+    if constexpr (MODE == IN_REAL) {
+      yr = (k < n0) ? double(static_cast<const T*>(in)[k]) : 0.0;
+      yi = 0;
+    } else {
+      const cplx<T> v = filtered_bin<T>(static_cast<const cplx<T>*>(in), rows[row], mo,
+                                        signed_bin(k, N), N - 1);
+      yr = v.x; yi = v.y;
+    }
+    const double ang = 6.283185307179586476925 * double((k * m) & (N - 1)) / double(N);
+    const double c = cos(ang), s = sin(ang);
+    sr += yr * c - yi * s;
+    si += yr * s + yi * c;
+  }
+  const long orow = (MODE == IN_REAL) ? 0 : long(rows[row].out_row);
+  out[orow * ldw + m] = mk<T>(T(sr), T(MODE == IN_REAL ? -si : si));
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_narrow: rows whose filter support is <= K = 2^logK bins.  N = K*R, n = R*m + r:
+//   W[R m + r] = sum_{q<K} ( Y[k(q)] e^{2 pi i k(q) r / N} ) e^{2 pi i q m / K},
+// k(q) = the only in-band bin congruent to q mod K.  grid = (R/TB, rows of this class);
+// PLANES layout, lanes run along r so that the stores of W are TB*sizeof(complex) contiguous.
+template <typename T>
+__global__ void __launch_bounds__(CWT_MAX_THREADS)
+k_narrow(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+         const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, int logK, int logTB,
+         cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const int N = 1 << logN, K = 1 << logK, logNT = logK - 4, NT = 1 << logNT;
+  const int logR = logN - logK;
+  const RowDesc rd = rows[blockIdx.y];
+  Geo<T, true> g;
+  g.logL = logK; g.logTB = logTB;
+  g.t = threadIdx.x & ((1 << logTB) - 1);
+  g.j = threadIdx.x >> logTB;
+  const unsigned r = (blockIdx.x << logTB) + g.t;
+
+  // phase 0: Y[q] = xhat[k(q)] * F[k(q)], q < K, shared by the TB FFTs of this workgroup
+  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
+  for (int q = threadIdx.x; q < K; q += blockDim.x) {
+    const int d = (q - rd.k_lo) & (K - 1);
+    ytile[q] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d, N - 1);
+  }
+  __syncthreads();
+
+  // phase 1: slot e <- Y[q_e] * e^{2 pi i k(q_e) r / N}, q_e = j + e*NT; the twiddle advances by
+  // e^{2 pi i NT r / N} per slot and by an extra e^{-2 pi i K r / N} when k(q) wraps around the band
+  T re[16], im[16];
+  {
+    const unsigned nm = unsigned(N - 1);
+    int d = (g.j - rd.k_lo) & (K - 1);
+    cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
+    const cplx<T> step = twn((unsigned(NT) * r) & nm);
+    const cplx<T> stepw = cmul<T>(step, twn((0u - (r << logK)) & nm));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const cplx<T> y = ytile[g.j + (e << logNT)];
+      re[e] = y.x * cur.x - y.y * cur.y;
+      im[e] = y.x * cur.y + y.y * cur.x;
+      const int dn = (d + NT) & (K - 1);
+      cur = cmul<T>(cur, dn < d ? stepw : step);
+      d = dn;
+    }
+  }
+  __syncthreads();  // ytile aliases the exchange buffer
+
+  wg_ifft<T, true>(re, im, lds, g, tw);
+
+  cplx<T>* wrow = W + long(rd.out_row) * ldw;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long n = (long(g.j + (e << logNT)) << logR) + r;
+    if (n < ncols) wrow[n] = mk<T>(re[e], im[e]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pass_a: first pass of the two-pass transform, N = R*K, input bin k = q + K*k1:
+//   Z[r][q] = e^{2 pi i q r / N} sum_{k1<R} Y[q + K k1] e^{2 pi i k1 r / R}
+// grid = (K/TQ, rows in chunk).  PLANES layout: lanes run along q (coalesced reads of xhat and
+// coalesced stores of Z rows).  MODE IN_REAL reads the zero-padded real signal instead.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(CWT_MAX_THREADS)
+k_pass_a(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,
+         const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, int logK, int logTQ, long n0,
+         cplx<T>* __restrict__ Z) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const int N = 1 << logN, logR = logN - logK, logNT = logR - 4, NT = 1 << logNT;
+  Geo<T, true> g;
+  g.logL = logR; g.logTB = logTQ;
+  g.t = threadIdx.x & ((1 << logTQ) - 1);
+  g.j = threadIdx.x >> logTQ;
+  const int q = (blockIdx.x << logTQ) + g.t;
+  T re[16], im[16];
+  if constexpr (MODE == IN_REAL) {
+    const T* x = static_cast<const T*>(in);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long k = q + (long(g.j + (e << logNT)) << logK);
+      re[e] = k < n0 ? x[k] : T(0);
+      im[e] = T(0);
+    }
+  } else {
+    const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
+    const RowDesc rd = rows[blockIdx.y];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = q + ((g.j + (e << logNT)) << logK);
+      const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
+      re[e] = v.x; im[e] = v.y;
+    }
+  }
+  wg_ifft<T, true>(re, im, lds, g, tw);
+  cplx<T>* z = Z + (long(blockIdx.y) << logN) + q;
+  cplx<T> cur = twn(unsigned(q) * unsigned(g.j));
+  const cplx<T> step = twn(unsigned(q) << logNT);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long r = g.j + (e << logNT);
+    z[r << logK] = mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
+    cur = cmul<T>(cur, step);
+  }
+}
+
+// k_pass_b: second pass: W[R m + r] = sum_{q<K} Z[r][q] e^{2 pi i q m / K}.
+// grid = (R/TB, rows in chunk).  ROWS layout for the FFT (coalesced reads of Z rows), then an LDS
+// transpose so that lanes run along r for the stores.  CONJ: store conj (forward transform).
+template <typename T, bool CONJ>
+__global__ void __launch_bounds__(CWT_MAX_THREADS)
+k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
+         const cplx<T>* __restrict__ tw, int logN, int logK, int logTB, cplx<T>* __restrict__ W,
+         long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const int logR = logN - logK, logNT = logK - 4, NT = 1 << logNT;
+  Geo<T, false> g;
+  g.logL = logK; g.logTB = logTB;
+  g.j = threadIdx.x & (NT - 1);
+  g.t = threadIdx.x >> logNT;
+  const long r0 = long(blockIdx.x) << logTB;
+  const cplx<T>* z = Z + (long(blockIdx.y) << logN) + ((r0 + g.t) << logK) + g.j;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> v = z[e << logNT];
+    re[e] = v.x; im[e] = v.y;
+  }
+  wg_ifft<T, false>(re, im, lds, g, tw);
+
+  // transpose: element (t, m) -> linear index m*TB + t; thread reads back linear tid + c*blockDim
+  // (every LDS read of wg_ifft is already fenced by the barrier that ends its last exchange)
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    lds[lds_swizzle<T>(((g.j + (e << logNT)) << logTB) | g.t)] = re[e];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) re[c] = lds[lds_swizzle<T>(threadIdx.x + c * blockDim.x)];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    lds[lds_swizzle<T>(((g.j + (e << logNT)) << logTB) | g.t)] = im[e];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) im[c] = lds[lds_swizzle<T>(threadIdx.x + c * blockDim.x)];
+
+  const long orow = rows ? long(rows[blockIdx.y].out_row) : 0;
+  cplx<T>* wrow = W + orow * ldw;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int idx = threadIdx.x + c * blockDim.x;
+    const long m = idx >> logTB, t = idx & ((1 << logTB) - 1);
+    const long n = (m << logR) + r0 + t;
+    if (n < ncols) wrow[n] = mk<T>(re[c], CONJ ? -im[c] : im[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icwt: out[n] = coeff * sum_j Re W[j, n] * w[j],  w[j] = 1/sqrt(s_j)   (wavelet.py:169-170)
+template <typename T>
+__global__ void k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int nrows,
+                       const T* __restrict__ w, T coeff, T* __restrict__ out) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  T acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+  int j = 0;
+  for (; j + 4 <= nrows; j += 4) {
+    acc0 += W[long(j) * ldw + n].x * w[j];
+    acc1 += W[long(j + 1) * ldw + n].x * w[j + 1];
+    acc2 += W[long(j + 2) * ldw + n].x * w[j + 2];
+    acc3 += W[long(j + 3) * ldw + n].x * w[j + 3];
+  }
+  for (; j < nrows; ++j) acc0 += W[long(j) * ldw + n].x * w[j];
+  out[n] = coeff * ((acc0 + acc1) + (acc2 + acc3));
+}
+
+}  // namespace cwt
