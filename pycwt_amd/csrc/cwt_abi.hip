@@ -469,14 +469,14 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
 
 int cwt_plan_destroy(cwt_plan* p) {
   if (!p) return CWT_OK;
-  hipSetDevice(p->device);
-  hipStreamSynchronize(p->stream);
-  for (auto& t : p->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-  for (auto e : p->free_events) hipEventDestroy(e);
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto e : p->free_events) (void)hipEventDestroy(e);
   void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW};
-  for (void* b : bufs) if (b) hipFree(b);
-  if (p->rows_pinned) hipHostFree(p->rows_pinned);
-  if (p->weights_pinned) hipHostFree(p->weights_pinned);
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (p->rows_pinned) (void)hipHostFree(p->rows_pinned);
+  if (p->weights_pinned) (void)hipHostFree(p->weights_pinned);
   delete p;
   return CWT_OK;
 }

@@ -35,3 +35,36 @@ def row_errors(W, Wref):
     per_row = num / np.where(den == 0, 1, den)
     l2 = np.linalg.norm((W - Wref).ravel()) / max(np.linalg.norm(Wref.ravel()), 1e-300)
     return per_row, l2
+
+
+@pytest.fixture(scope="session")
+def emu_library():
+    """libcwt_emu.so: the kernel sources compiled against the CPU stand-in for HIP (tests/emu)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from pycwt_amd import _hip
+    return _hip.Library(build_emu.build())
+
+
+@pytest.fixture()
+def emulated(emu_library, monkeypatch):
+    """Route the Python shim to the emulated library for one test (test-only monkeypatch; the
+    product resolves pycwt_amd/libcwt_hip.so and nothing else)."""
+    from pycwt_amd import _hip, wavelet
+    monkeypatch.setattr(_hip, "_default", emu_library)
+    monkeypatch.setattr(wavelet, "_plans", {})
+    yield emu_library
+    for p in wavelet._plans.values():
+        p.close()
+
+
+@pytest.fixture(scope="session")
+def hip_library():
+    """The product library on a real GPU (gpu-marked tests only)."""
+    from pycwt_amd import _build, _hip
+    _build.build()
+    lib = _hip.load()
+    assert lib.backend() == "hip-gfx950"
+    if lib.device_count() < 1:
+        pytest.fail("gpu test selected but no GPU is visible")
+    return lib

@@ -1,0 +1,47 @@
+"""The C-ABI library builds for gfx950, loads on a box without a GPU, and exports every symbol
+include/cwt_hip.h declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from pycwt_amd import _build, _hip
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "cwt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cwt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(name for name, _, _ in _hip.SYMBOLS)
+
+
+def test_product_library_builds_loads_and_exports_all_symbols():
+    path = _build.build()
+    assert path.endswith("pycwt_amd/libcwt_hip.so") and os.path.exists(path)
+    lib = _hip.Library(path)            # getattr on every symbol; AttributeError if one is missing
+    assert lib.backend() == "hip-gfx950"
+    assert lib.cwt_last_error() is not None
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _hip.Library(str(tmp_path / "libcwt_hip.so"))
+
+
+def test_argument_validation_without_gpu(emu_library):
+    import ctypes as C
+    lib = emu_library
+    h = C.c_void_p()
+    assert lib.cwt_plan_create(C.byref(h), 0, 1000, 64, 4) < 0          # not a power of two
+    assert b"power of two" in lib.cwt_last_error()
+    assert lib.cwt_plan_create(C.byref(h), 0, 1024, 16, 4) < 0          # bad precision
+    assert lib.cwt_plan_create(C.byref(h), 0, 1024, 64, 0) < 0          # bad max_rows
+    assert lib.cwt_plan_create(C.byref(h), 0, 1024, 64, 4) == 0
+    assert lib.cwt_plan_set_option(h, b"nonsense", 1) < 0
+    assert lib.cwt_plan_set_option(h, b"lmax", 100) < 0
+    assert lib.cwt_forward_fft(h, None, 10, None) < 0
+    assert lib.cwt_plan_destroy(h) == 0

@@ -1,0 +1,92 @@
+"""pycwt_amd.cwt / icwt (the drop-in Python API) against the reference-generated fixtures, with the
+kernels running on the CPU emulation.  Mirrors how a pycwt user calls the functions
+(sample/simple_sample.py:58-60: positional arguments, mother instance or name)."""
+import numpy as np
+import pytest
+
+import pycwt_amd
+from conftest import load_golden, row_errors
+
+
+def check_tuple(out, g, tol=1e-12):
+    W, sj, freqs, coi, fft, fftfreqs = out
+    assert W.shape == g["W"].shape and W.dtype == np.complex128
+    per_row, l2 = row_errors(W, g["W"])
+    assert per_row.max() < tol and l2 < tol
+    np.testing.assert_allclose(sj, g["sj"], rtol=1e-15)
+    np.testing.assert_allclose(freqs, g["freqs"], rtol=1e-15)
+    np.testing.assert_allclose(coi, g["coi"], rtol=1e-15)
+    np.testing.assert_allclose(fft, g["fft"], rtol=0, atol=tol * np.abs(g["fft"]).max())
+    np.testing.assert_allclose(fftfreqs, g["fftfreqs"], rtol=1e-15)
+
+
+def test_nino3_simple_sample_recipe(emulated):
+    g = load_golden("nino3_simple")
+    mother = pycwt_amd.Morlet(6)
+    out = pycwt_amd.cwt(g["x"], 0.25, 1 / 12, 0.5, 84, mother)          # positional, as the sample does
+    check_tuple(out, g)
+    iw = pycwt_amd.icwt(out[0], out[1], 0.25, 1 / 12, mother)
+    assert iw.dtype == g["icwt"].dtype == np.complex128                 # Morlet psi(0) is complex
+    np.testing.assert_allclose(iw, g["icwt"], rtol=1e-11, atol=1e-12)
+
+
+def test_nino3_default_scales_and_string_mother(emulated):
+    g = load_golden("nino3_default")
+    out = pycwt_amd.cwt(list(g["x"]), 0.25, wavelet="morlet")           # list input is accepted
+    check_tuple(out, g)
+
+
+@pytest.mark.parametrize("name,cls", [("morlet", pycwt_amd.Morlet), ("paul", pycwt_amd.Paul),
+                                      ("dog", pycwt_amd.DOG)])
+def test_small_fixture_per_mother_including_nan_row_drop(emulated, name, cls):
+    g = load_golden("small_" + name)
+    out = pycwt_amd.cwt(g["x"], 0.5, 0.25, -1, -1, cls())
+    check_tuple(out, g)                                                 # shape check covers the Paul row drop
+    iw = pycwt_amd.icwt(out[0], out[1], 0.5, 0.25, name)
+    assert iw.dtype == g["icwt"].dtype
+    np.testing.assert_allclose(iw, g["icwt"], rtol=1e-11, atol=1e-12)
+
+
+def test_freqs_argument_and_mexican_hat(emulated):
+    g = load_golden("small_dog")
+    f = g["freqs"][[3, 10, 20]]
+    W, sj, freqs, *_ = pycwt_amd.cwt(g["x"], 0.5, freqs=f, wavelet="mexicanhat")
+    per_row, _ = row_errors(W, g["W"][[3, 10, 20]])
+    assert per_row.max() < 1e-12
+    np.testing.assert_allclose(sj, g["sj"][[3, 10, 20]], rtol=1e-14)
+
+
+def test_fp32_engine_within_1e3(emulated):
+    g = load_golden("small_morlet")
+    W = pycwt_amd.cwt(g["x"].astype(np.float32), 0.5, 0.25, precision=32)[0]
+    assert W.dtype == np.complex128
+    per_row, l2 = row_errors(W, g["W"])
+    assert per_row.max() < 1e-3 and l2 < 1e-4
+
+
+def test_error_conventions(emulated):
+    x = np.zeros(64)
+    with pytest.raises(KeyError):                       # wavelet.py:658-661
+        pycwt_amd.cwt(x, 1.0, wavelet="Morlet")
+    with pytest.raises(Warning, match="dimensions"):    # wavelet.py:166
+        pycwt_amd.icwt(np.zeros((4, 64), complex), np.ones(5), 1.0)
+
+    class Custom:
+        def flambda(self): return 1.0
+        def coi(self): return 1.0
+        def psi_ft(self, f): return f * 0
+    with pytest.raises(NotImplementedError):
+        pycwt_amd.cwt(x, 1.0, wavelet=Custom())
+
+
+def test_mother_protocol_matches_reference_constants():
+    m = pycwt_amd.Morlet()
+    assert (m.cdelta, m.gamma, m.deltaj0, m.dofmin, m.name) == (0.776, 2.32, 0.60, 2, "Morlet")
+    assert abs(m.flambda() - 1.0330436477492537) < 1e-15
+    assert pycwt_amd.Morlet(5).cdelta == -1
+    p = pycwt_amd.Paul()
+    assert (p.cdelta, p.gamma, p.deltaj0, p.dofmin) == (1.132, 1.17, 1.5, 2)
+    d = pycwt_amd.DOG(6)
+    assert (d.cdelta, d.gamma, d.deltaj0, d.dofmin) == (1.966, 1.37, 0.97, 1)
+    assert pycwt_amd.MexicanHat().m == 2 and pycwt_amd.MexicanHat().name == "Mexican Hat"
+    assert isinstance(pycwt_amd.Morlet().psi(0), complex) or np.iscomplexobj(pycwt_amd.Morlet().psi(0))
