@@ -54,7 +54,7 @@ def cpu_baseline(x, dt, kind, param, sj_all, budget_s=20.0):
     timed on a bounded sample of rows of the same workload."""
     from oracle import cwt_oracle as orc
     m = orc.Mother(kind, int(param) if kind else param)
-    idx = np.linspace(0, len(sj_all) - 1, 8).round().astype(int)
+    idx = np.unique(np.linspace(0, len(sj_all) - 1, 32).round().astype(int))
     orc.cwt_rows(x[:4096], dt, sj_all[idx[:2]], m)            # warm-up (imports, pocketfft plan)
     t0 = time.perf_counter()
     done = 0
