@@ -68,6 +68,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "narrow_max_k" largest per-row transform length of that path (power of two)
  *   "lmax"         largest single-workgroup FFT length (power of two, <= 4096)
  *   "wg_points"    complex points per workgroup of the fused kernels
+ *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
 /* Block the host until everything queued by this plan has finished. */

@@ -64,6 +64,7 @@ struct cwt_plan {
   int loglmax = 12;
   int log_wg_points = 13;
   int profile = 0;
+  int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
@@ -297,6 +298,69 @@ int ensure_z(cwt_plan* p, int rows) {
   return CWT_OK;
 }
 
+
+// ---- compile-time specialised kernels for the default geometry --------------------------------
+template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 : 14; }
+
+template <typename T, int LOGK>
+void launch_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo,
+                      cplx<T>* W, int64_t ldw, int64_t ncols) {
+  constexpr int LOGP = default_logp<T>();
+  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP>), dim3(1u << (p->logN - LOGP), g.count),
+                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
+                     p->rows_dev + g.first, mo, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw),
+                     long(ncols));
+}
+
+template <typename T>
+bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo, cplx<T>* W,
+                   int64_t ldw, int64_t ncols) {
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
+  switch (g.logK) {
+    case 4: launch_narrow_ct<T, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 5: launch_narrow_ct<T, 5>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 6: launch_narrow_ct<T, 6>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 7: launch_narrow_ct<T, 7>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 8: launch_narrow_ct<T, 8>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 9: launch_narrow_ct<T, 9>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 10: launch_narrow_ct<T, 10>(p, g, xhat, mo, W, ldw, ncols); return true;
+    default: return false;
+  }
+}
+
+template <typename T, int LOGR, int MODE>
+void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo, long n0) {
+  constexpr int LOGP = default_logp<T>();
+  hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LOGP, MODE>), dim3(1u << (p->logN - LOGP), cnt),
+                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, in, rows, mo,
+                     tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, static_cast<cplx<T>*>(p->Z));
+}
+
+template <typename T, int MODE>
+bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
+                   long n0) {
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
+  switch (logR) {
+    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0); return true;
+    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0); return true;
+    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0); return true;
+    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0); return true;
+    default: return false;
+  }
+}
+
+template <typename T, bool CONJ>
+bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw,
+                   int64_t ncols) {
+  constexpr int LOGP = default_logp<T>();
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != LOGP || logK != 10) return false;
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  hipLaunchKernelGGL((k_pass_b_ct<T, 10, LOGP, CONJ>), dim3(1u << (p->logN - LOGP), cnt),
+                     dim3(1 << (LOGP - 4)), lds, p->stream, static_cast<const cplx<T>*>(p->Z), rows,
+                     tw_table<T>(p, 10), p->logN, W, long(ldw), long(ncols));
+  return true;
+}
+
 template <typename T>
 int forward_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   const int logN = p->logN;
@@ -324,12 +388,14 @@ int forward_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   const int threads = 1 << (logP - 4);
   rc = timed_launch(p, KC_FWD_A, [&] {
+    if (try_pass_a_ct<T, IN_REAL>(p, logR, x_dev, nullptr, 1, mo, long(n0))) return;
     hipLaunchKernelGGL((k_pass_a<T, IN_REAL>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
                        x_dev, (const RowDesc*)nullptr, mo, tw_table<T>(p, logR), twn_of<T>(p), logN,
                        logK, logP - logR, long(n0), static_cast<cplx<T>*>(p->Z));
   });
   if (rc) return rc;
   return timed_launch(p, KC_FWD_B, [&] {
+    if (try_pass_b_ct<T, true>(p, logK, nullptr, 1, out, p->N, p->N)) return;
     hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
                        static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
                        logN, logK, logP - logK, out, long(p->N), long(p->N));
@@ -367,6 +433,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   for (const auto& g : p->narrow_groups) {
     rc = timed_launch(p, KC_NARROW, [&] {
+      if (try_narrow_ct<T>(p, g, xhat, mo, W, ldw, ncols)) return;
       hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
                          xhat, p->rows_dev + g.first, mo, tw_table<T>(p, g.logK), twn_of<T>(p), logN,
                          g.logK, logP - g.logK, W, long(ldw), long(ncols));
@@ -382,12 +449,14 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       const int cnt = std::min(chunk, p->n_wide - first);
       const RowDesc* rows = p->rows_dev + p->wide_first + first;
       rc = timed_launch(p, KC_PASS_A, [&] {
+        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L)) return;
         hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
                            p->stream, xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK,
                            logP - logR, 0L, static_cast<cplx<T>*>(p->Z));
       });
       if (rc) return rc;
       rc = timed_launch(p, KC_PASS_B, [&] {
+        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols)) return;
         hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
                            p->stream, static_cast<const cplx<T>*>(p->Z), rows, tw_table<T>(p, logK), logN,
                            logK, logP - logK, W, long(ldw), long(ncols));
@@ -457,6 +526,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->logN = ilog2(nfft);
   p->prec = precision;
   p->max_rows = max_rows;
+  p->log_wg_points = precision == 64 ? 13 : 14;
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   if (!rc && hipMalloc(reinterpret_cast<void**>(&p->rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
@@ -504,6 +574,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "lmax") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "lmax: power of two in [16,4096]"); p->loglmax = ilog2(value); }
   else if (k == "wg_points") { if (!pow2(value) || value < 256 || value > 16384) return fail(CWT_EINVAL, "wg_points: power of two in [256,16384]"); p->log_wg_points = ilog2(value); }
   else if (k == "profile") p->profile = value != 0;
+  else if (k == "ct") p->use_ct = value != 0;
   else return fail(CWT_EINVAL, "unknown option " + k);
   if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
   return CWT_OK;

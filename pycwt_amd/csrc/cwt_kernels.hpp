@@ -53,8 +53,31 @@ struct TwN {
   }
 };
 
-__device__ __forceinline__ double exp_(double x) { return exp(x); }
-__device__ __forceinline__ float exp_(float x) { return expf(x); }
+// exp(x) for x <= 0 (every profile argument is non-positive inside the filter's support).
+// fp64: n = rint(x*log2 e), Cody-Waite reduction to |f| <= ln2/2, degree-13 Taylor polynomial
+// (truncation 4e-18), ldexp; ~19 instructions and 1-2 ulp, against ~40 for the library call.
+__device__ __forceinline__ double exp_(double x) {
+  const double n = rint(x * 1.4426950408889634074);
+  double f = fma(n, -6.93147180369123816490e-01, x);
+  f = fma(n, -1.90821492927058770002e-10, f);
+  double p = 1.6059043836821614599e-10;              // 1/13!
+  p = fma(p, f, 2.0876756987868098979e-09);          // 1/12!
+  p = fma(p, f, 2.5052108385441718775e-08);          // 1/11!
+  p = fma(p, f, 2.7557319223985890653e-07);          // 1/10!
+  p = fma(p, f, 2.7557319223985890653e-06);          // 1/9!
+  p = fma(p, f, 2.4801587301587301587e-05);          // 1/8!
+  p = fma(p, f, 1.9841269841269841270e-04);          // 1/7!
+  p = fma(p, f, 1.3888888888888888889e-03);          // 1/6!
+  p = fma(p, f, 8.3333333333333333333e-03);          // 1/5!
+  p = fma(p, f, 4.1666666666666666667e-02);          // 1/4!
+  p = fma(p, f, 1.6666666666666666667e-01);          // 1/3!
+  p = fma(p, f, 0.5);
+  p = fma(p, f, 1.0);
+  p = fma(p, f, 1.0);
+  const double nc = n < -1100.0 ? -1100.0 : n;       // deep underflow -> 0 without int overflow
+  return ldexp(p, int(nc));
+}
+__device__ __forceinline__ float exp_(float x) { return __expf(x); }
 
 template <typename T>
 __device__ __forceinline__ T ipow(T b, int e) {
@@ -329,6 +352,159 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const long m = idx >> logTB, t = idx & ((1 << logTB) - 1);
     const long n = (m << logR) + r0 + t;
     if (n < ncols) wrow[n] = mk<T>(re[c], CONJ ? -im[c] : im[c]);
+  }
+}
+
+// =============================================================================================
+// Compile-time specialised versions of k_narrow / k_pass_a / k_pass_b for the default geometry
+// (LOGP = log2 of the points per workgroup: 13 for fp64, 14 for fp32).  Same math and same launch
+// grids as the generic kernels above; the host picks them when the geometry matches.
+// Global accesses are written as (uniform pointer)[32-bit lane offset] so that they compile to
+// SGPR-base + VGPR-offset instructions instead of 64-bit per-lane address arithmetic.
+template <typename T, int LOGK, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
+            long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
+  using F = ct::Fft<T, LOGK, LOGTB, true>;
+  const int N = 1 << logN, logR = logN - LOGK;
+  const RowDesc rd = rows[blockIdx.y];
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTB) - 1);
+  f.j = threadIdx.x >> LOGTB;
+  const unsigned r = (blockIdx.x << LOGTB) + f.t;
+
+  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
+  for (int q = threadIdx.x; q < K; q += (1 << (LOGP - 4))) {
+    const int d = (q - rd.k_lo) & (K - 1);
+    ytile[q] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d, N - 1);
+  }
+  __syncthreads();
+  T re[16], im[16];
+  {
+    const unsigned nm = unsigned(N - 1);
+    int d = (f.j - rd.k_lo) & (K - 1);
+    cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
+    const cplx<T> step = twn((unsigned(NT) * r) & nm);
+    const cplx<T> stepw = cmul<T>(step, twn((0u - (r << LOGK)) & nm));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const cplx<T> y = ytile[f.j + e * NT];
+      re[e] = y.x * cur.x - y.y * cur.y;
+      im[e] = y.x * cur.y + y.y * cur.x;
+      const int dn = (d + NT) & (K - 1);
+      cur = cmul<T>(cur, dn < d ? stepw : step);
+      d = dn;
+    }
+  }
+  __syncthreads();
+  f.run(re, im, lds, tw);
+  cplx<T>* wrow = W + long(rd.out_row) * ldw;
+  const unsigned off = (unsigned(f.j) << logR) + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const unsigned step_e = unsigned(e * NT) << logR;
+    if (long(off) + step_e < ncols) (wrow + step_e)[off] = mk<T>(re[e], im[e]);
+  }
+}
+
+template <typename T, int LOGR, int LOGP, int MODE>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,
+            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, long n0, cplx<T>* __restrict__ Z) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int LOGTQ = LOGP - LOGR, LOGNT = LOGR - 4, NT = 1 << LOGNT;
+  using F = ct::Fft<T, LOGR, LOGTQ, true>;
+  const int N = 1 << logN, logK = logN - LOGR;
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTQ) - 1);
+  f.j = threadIdx.x >> LOGTQ;
+  const unsigned q = (blockIdx.x << LOGTQ) + f.t;
+  const unsigned k0 = q + (unsigned(f.j) << logK);        // bin of slot 0; slot e adds (e*NT) << logK
+  T re[16], im[16];
+  if constexpr (MODE == IN_REAL) {
+    const T* x = static_cast<const T*>(in);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned step_e = unsigned(e * NT) << logK;
+      re[e] = (long(k0) + step_e < n0) ? (x + step_e)[k0] : T(0);
+      im[e] = T(0);
+    }
+  } else {
+    const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
+    const RowDesc rd = rows[blockIdx.y];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = int(k0 + (unsigned(e * NT) << logK));
+      const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
+      re[e] = v.x; im[e] = v.y;
+    }
+  }
+  f.run(re, im, lds, tw);
+  cplx<T>* z = Z + (long(blockIdx.y) << logN);
+  const unsigned off = (unsigned(f.j) << logK) + q;
+  cplx<T> cur = twn(q * unsigned(f.j));
+  const cplx<T> step = twn(q << LOGNT);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    (z + (long(e * NT) << logK))[off] =
+        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
+    cur = cmul<T>(cur, step);
+  }
+}
+
+template <typename T, int LOGK, int LOGP, bool CONJ>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
+            const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, BD = 1 << (LOGP - 4);
+  using F = ct::Fft<T, LOGK, LOGTB, false>;
+  const int logR = logN - LOGK;
+  F f;
+  f.j = threadIdx.x & (NT - 1);
+  f.t = threadIdx.x >> LOGNT;
+  const unsigned r0 = blockIdx.x << LOGTB;
+  const cplx<T>* z = Z + (long(blockIdx.y) << logN) + (long(r0) << LOGK);
+  const unsigned zoff = (unsigned(f.t) << LOGK) + f.j;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> v = (z + e * NT)[zoff];
+    re[e] = v.x; im[e] = v.y;
+  }
+  f.run(re, im, lds, tw);
+
+  // LDS transpose (t, m) -> m*TB + t with one pad element per 16; reads are linear in tid
+  constexpr int TS = (BD) + (BD >> 4);                    // physical stride of 512 (or 1024) elements
+  const int wa = (f.j << LOGTB) + f.t, wbase = wa + (wa >> 4);
+  const int rbase = int(threadIdx.x) + (int(threadIdx.x) >> 4);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lds[wbase + e * TS] = re[e];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) re[c] = lds[rbase + c * TS];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lds[wbase + e * TS] = im[e];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) im[c] = lds[rbase + c * TS];
+
+  const long orow = rows ? long(rows[blockIdx.y].out_row) : 0;
+  cplx<T>* wrow = W + orow * ldw;
+  const unsigned m0 = threadIdx.x >> LOGTB, tt = threadIdx.x & ((1 << LOGTB) - 1);
+  const unsigned off = (m0 << logR) + r0 + tt;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const unsigned step_c = unsigned(c * (BD >> LOGTB)) << logR;
+    if (long(off) + step_c < ncols) (wrow + step_c)[off] = mk<T>(re[c], CONJ ? -im[c] : im[c]);
   }
 }
 

@@ -235,4 +235,97 @@ __device__ __forceinline__ void wg_ifft(T (&re)[16], T (&im)[16], T* lds, const 
   else if (rem == 3) partial_stage<T, 8>(re, im, g.j, logL, logNs, tw);
 }
 
+
+// =============================================================================================
+// Compile-time specialised engine for the hot geometries (same algorithm as wg_ifft above).
+// All strides are constants, so every LDS access is `base register + immediate offset`, the
+// stage loop disappears, and the register allocator sees straight-line code.
+//
+// LDS layouts (element = one real of type T; re and im planes are exchanged one after the other):
+//   PLANES: element pos of FFT t at pos*TB + t, no padding.  Reads (consecutive lanes ->
+//           consecutive elements) are conflict free; stage-0 writes with TB = 8 (fp64) are a
+//           harmless 2-way conflict, everything else is conflict free.
+//   ROWS  : a = t*L + pos, physical index a + (a >> 4)  (one pad element per 16): the stride-16
+//           Stockham writes become stride 17, and all offsets stay additive because every
+//           stride used is a multiple of 16 elements.  Requires L >= 256.
+// Synchronisation: PLANES -> workgroup barriers.  ROWS with one FFT per wavefront (L = 1024) ->
+// no s_barrier at all: LDS operations of one wave execute in order, so a compiler-level fence is
+// enough between the write and the read phase.
+namespace ct {
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int LOGL, int LOGTB, bool PLANES>
+struct Fft {
+  static constexpr int L = 1 << LOGL, TB = 1 << LOGTB, LOGNT = LOGL - 4, NT = 1 << LOGNT;
+  static constexpr int NFULL = LOGL / 4, REM = LOGL % 4;
+  static constexpr bool WAVE_LOCAL = !PLANES && NT == 64;   // one FFT == one wavefront
+  static_assert(PLANES || LOGL >= 8, "ROWS layout needs L >= 256");
+  static constexpr int LDS_ELEMS = PLANES ? (TB * L) : (TB * L + ((TB * L) >> 4));
+
+  int t, j;   // FFT index in the workgroup, thread index in the FFT
+
+  __device__ __forceinline__ static void sync() {
+    if constexpr (WAVE_LOCAL) wave_sync(); else __syncthreads();
+  }
+  // physical element index of position pos (pos may carry any multiple-of-16 part)
+  __device__ __forceinline__ int phys(int pos) const {
+    if constexpr (PLANES) return (pos << LOGTB) + t;
+    else { const int a = (t << LOGL) + pos; return a + (a >> 4); }
+  }
+  // physical stride that corresponds to a logical stride (multiple of 16 for ROWS)
+  static constexpr int pstride(int s) { return PLANES ? (s << LOGTB) : (s + (s >> 4)); }
+
+  // one real plane: slot n -> position wbase + n*Ns ; slot e <- position j + e*NT
+  template <int LOGNS>
+  __device__ __forceinline__ void exchange(T (&v)[16], T* lds, int wphys, int rphys) const {
+    constexpr int WS = (LOGNS == 0) ? (PLANES ? TB : 1) : pstride(1 << LOGNS);
+    constexpr int RS = (NT >= 16 || PLANES) ? pstride(NT) : 0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) lds[wphys + n * WS] = v[n];
+    sync();
+    if constexpr (NT >= 16 || PLANES) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = lds[rphys + e * RS];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = lds[phys(j + e * NT)];
+    }
+    sync();
+  }
+
+  template <int S>
+  __device__ __forceinline__ void full_stage(T (&re)[16], T (&im)[16], T* lds,
+                                             const cplx<T>* __restrict__ tw, int rphys) const {
+    constexpr int LOGNS = 4 * S;
+    const int k = j & ((1 << LOGNS) - 1);
+    if constexpr (S > 0) {
+      const cplx<T> w = tw[k << (LOGL - LOGNS - 4)];
+      twiddle_chain<T, 16>(re, im, w.x, w.y);
+    }
+    bfly16<T>(re, im);
+    if constexpr (S == NFULL - 1 && REM == 0) return;
+    const int wphys = phys(((j - k) << 4) + k);
+    exchange<LOGNS>(re, lds, wphys, rphys);
+    exchange<LOGNS>(im, lds, wphys, rphys);
+  }
+
+  // in: slot e = x[j + e*NT]; out: slot e = X[j + e*NT].  lds: LDS_ELEMS reals.
+  __device__ __forceinline__ void run(T (&re)[16], T (&im)[16], T* lds,
+                                      const cplx<T>* __restrict__ tw) const {
+    const int rphys = phys(j);
+    full_stage<0>(re, im, lds, tw, rphys);
+    if constexpr (NFULL >= 2) full_stage<1>(re, im, lds, tw, rphys);
+    if constexpr (NFULL >= 3) full_stage<2>(re, im, lds, tw, rphys);
+    if constexpr (REM == 1) partial_stage<T, 2>(re, im, j, LOGL, 4 * NFULL, tw);
+    if constexpr (REM == 2) partial_stage<T, 4>(re, im, j, LOGL, 4 * NFULL, tw);
+    if constexpr (REM == 3) partial_stage<T, 8>(re, im, j, LOGL, 4 * NFULL, tw);
+  }
+};
+
+}  // namespace ct
 }  // namespace cwt

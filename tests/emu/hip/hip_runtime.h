@@ -55,6 +55,11 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 #define blockDim (hipemu::cur->bdim)
 #define gridDim (hipemu::cur->gdim)
 #define __syncthreads() hipemu::barrier()
+// wavefront-level sync: every fiber of the block runs the same barrier sequence, so the block-wide
+// round-robin yield is a (stronger) stand-in
+#define __builtin_amdgcn_wave_barrier() hipemu::barrier()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __expf(x) expf(x)
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::cur->smem);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
