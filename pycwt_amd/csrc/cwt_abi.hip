@@ -58,13 +58,14 @@ struct cwt_plan {
   int max_rows = 0;
   hipStream_t stream = nullptr;
   // options
-  int chunk_rows = 4;
+  int chunk_rows = 12;     // 12 x 16 MiB (N = 2^20, fp64) of intermediate stays inside the 256 MiB Infinity Cache
   int narrow = 1;
   int narrow_max_logk = 10;
   int loglmax = 12;
   int log_wg_points = 13;
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
+  int overlap = 1;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
@@ -90,6 +91,8 @@ struct cwt_plan {
   int split[3] = {0, 0, 0};
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
+  hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
+  hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
 };
@@ -123,7 +126,7 @@ int get_event(cwt_plan* p, hipEvent_t* e) {
 // Runs `launch()` (which enqueues exactly one kernel class) and, when profiling, brackets it with
 // HIP events on the plan's stream.
 template <class F>
-int timed_launch(cwt_plan* p, int cls, F&& launch) {
+int timed_launch(cwt_plan* p, int cls, F&& launch, hipStream_t stream) {
   if (!p->profile) {
     launch();
     HIPCHECK(hipGetLastError());
@@ -135,12 +138,16 @@ int timed_launch(cwt_plan* p, int cls, F&& launch) {
   if (rc) return rc;
   rc = get_event(p, &t.b);
   if (rc) return rc;
-  HIPCHECK(hipEventRecord(t.a, p->stream));
+  HIPCHECK(hipEventRecord(t.a, stream));
   launch();
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipEventRecord(t.b, p->stream));
+  HIPCHECK(hipEventRecord(t.b, stream));
   p->timed.push_back(t);
   return CWT_OK;
+}
+template <class F>
+int timed_launch(cwt_plan* p, int cls, F&& launch) {
+  return timed_launch(p, cls, launch, p->stream);
 }
 
 template <typename T>
@@ -329,35 +336,36 @@ bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, c
 }
 
 template <typename T, int LOGR, int MODE>
-void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo, long n0) {
+void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo, long n0,
+                      cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
   hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LOGP, MODE>), dim3(1u << (p->logN - LOGP), cnt),
-                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, in, rows, mo,
-                     tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, static_cast<cplx<T>*>(p->Z));
+                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), st, in, rows, mo,
+                     tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, Z);
 }
 
 template <typename T, int MODE>
 bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
-                   long n0) {
+                   long n0, cplx<T>* Z, hipStream_t st) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
   switch (logR) {
-    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0); return true;
-    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0); return true;
-    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0); return true;
-    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0); return true;
+    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
+    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
+    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
+    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
     default: return false;
   }
 }
 
 template <typename T, bool CONJ>
 bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw,
-                   int64_t ncols) {
+                   int64_t ncols, const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != LOGP || logK != 10) return false;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
   hipLaunchKernelGGL((k_pass_b_ct<T, 10, LOGP, CONJ>), dim3(1u << (p->logN - LOGP), cnt),
-                     dim3(1 << (LOGP - 4)), lds, p->stream, static_cast<const cplx<T>*>(p->Z), rows,
-                     tw_table<T>(p, 10), p->logN, W, long(ldw), long(ncols));
+                     dim3(1 << (LOGP - 4)), lds, st, Z, rows, tw_table<T>(p, 10), p->logN, W, long(ldw),
+                     long(ncols));
   return true;
 }
 
@@ -388,14 +396,14 @@ int forward_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   const int threads = 1 << (logP - 4);
   rc = timed_launch(p, KC_FWD_A, [&] {
-    if (try_pass_a_ct<T, IN_REAL>(p, logR, x_dev, nullptr, 1, mo, long(n0))) return;
+    if (try_pass_a_ct<T, IN_REAL>(p, logR, x_dev, nullptr, 1, mo, long(n0), static_cast<cplx<T>*>(p->Z), p->stream)) return;
     hipLaunchKernelGGL((k_pass_a<T, IN_REAL>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
                        x_dev, (const RowDesc*)nullptr, mo, tw_table<T>(p, logR), twn_of<T>(p), logN,
                        logK, logP - logR, long(n0), static_cast<cplx<T>*>(p->Z));
   });
   if (rc) return rc;
   return timed_launch(p, KC_FWD_B, [&] {
-    if (try_pass_b_ct<T, true>(p, logK, nullptr, 1, out, p->N, p->N)) return;
+    if (try_pass_b_ct<T, true>(p, logK, nullptr, 1, out, p->N, p->N, static_cast<const cplx<T>*>(p->Z), p->stream)) return;
     hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
                        static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
                        logN, logK, logP - logK, out, long(p->N), long(p->N));
@@ -431,6 +439,47 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int logP = std::min(p->log_wg_points, logN);
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
+  if (p->n_wide) {
+    const int logK = two_pass_logk(p), logR = logN - logK;
+    const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));
+    const int nchunks = (p->n_wide + chunk - 1) / chunk;
+    const bool pipelined = p->overlap && nchunks > 1;
+    rc = ensure_z(p, pipelined ? 2 * chunk : chunk);
+    if (rc) return rc;
+    // Pipelined: pass A of chunk c+1 (latency/VALU bound) runs on side stream 0 beside pass B of
+    // chunk c (memory bound) on side stream 1, through two intermediate buffers.
+    hipStream_t sa = pipelined ? p->side[0] : p->stream, sb = pipelined ? p->side[1] : p->stream;
+    if (pipelined) {
+      HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
+      HIPCHECK(hipStreamWaitEvent(sa, p->ev_fork, 0));
+      HIPCHECK(hipStreamWaitEvent(sb, p->ev_fork, 0));
+    }
+    for (int c = 0; c < nchunks; ++c) {
+      const int first = c * chunk, cnt = std::min(chunk, p->n_wide - first), buf = pipelined ? (c & 1) : 0;
+      const RowDesc* rows = p->rows_dev + p->wide_first + first;
+      cplx<T>* Z = static_cast<cplx<T>*>(p->Z) + size_t(buf) * size_t(chunk) * size_t(p->N);
+      if (pipelined && c >= 2) HIPCHECK(hipStreamWaitEvent(sa, p->ev_b[buf], 0));   // buffer is free again
+      rc = timed_launch(p, KC_PASS_A, [&] {
+        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, Z, sa)) return;
+        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sa,
+                           xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, Z);
+      }, sa);
+      if (rc) return rc;
+      if (pipelined) {
+        HIPCHECK(hipEventRecord(p->ev_a[buf], sa));
+        HIPCHECK(hipStreamWaitEvent(sb, p->ev_a[buf], 0));
+      }
+      rc = timed_launch(p, KC_PASS_B, [&] {
+        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, sb)) return;
+        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sb,
+                           static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), logN, logK, logP - logK, W,
+                           long(ldw), long(ncols));
+      }, sb);
+      if (rc) return rc;
+      if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
+    }
+  }
+  // band-limited rows go to the plan's own stream and overlap with the two-pass pipeline
   for (const auto& g : p->narrow_groups) {
     rc = timed_launch(p, KC_NARROW, [&] {
       if (try_narrow_ct<T>(p, g, xhat, mo, W, ldw, ncols)) return;
@@ -441,27 +490,11 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     if (rc) return rc;
   }
   if (p->n_wide) {
-    const int logK = two_pass_logk(p), logR = logN - logK;
     const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));
-    rc = ensure_z(p, chunk);
-    if (rc) return rc;
-    for (int first = 0; first < p->n_wide; first += chunk) {
-      const int cnt = std::min(chunk, p->n_wide - first);
-      const RowDesc* rows = p->rows_dev + p->wide_first + first;
-      rc = timed_launch(p, KC_PASS_A, [&] {
-        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L)) return;
-        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
-                           p->stream, xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK,
-                           logP - logR, 0L, static_cast<cplx<T>*>(p->Z));
-      });
-      if (rc) return rc;
-      rc = timed_launch(p, KC_PASS_B, [&] {
-        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols)) return;
-        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds,
-                           p->stream, static_cast<const cplx<T>*>(p->Z), rows, tw_table<T>(p, logK), logN,
-                           logK, logP - logK, W, long(ldw), long(ncols));
-      });
-      if (rc) return rc;
+    const int nchunks = (p->n_wide + chunk - 1) / chunk;
+    if (p->overlap && nchunks > 1) {   // join: every pass A is followed by its pass B on side stream 1
+      HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
+      HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
     }
   }
   return CWT_OK;
@@ -529,6 +562,12 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->log_wg_points = precision == 64 ? 13 : 14;
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
+  for (int i = 0; i < 2 && !rc; ++i) {
+    if (hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&p->ev_a[i]) != hipSuccess || hipEventCreate(&p->ev_b[i]) != hipSuccess)
+      rc = fail(CWT_EHIP, "cannot create side streams/events");
+  }
+  if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipMalloc(reinterpret_cast<void**>(&p->rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
     rc = fail(CWT_ENOMEM, "row table allocation failed");
   if (!rc && hipMalloc(&p->weights_dev, size_t(max_rows) * sizeof(double)) != hipSuccess)
@@ -546,6 +585,12 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (!p) return CWT_OK;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
+  for (int i = 0; i < 2; ++i) {
+    if (p->side[i]) { (void)hipStreamSynchronize(p->side[i]); (void)hipStreamDestroy(p->side[i]); }
+    if (p->ev_a[i]) (void)hipEventDestroy(p->ev_a[i]);
+    if (p->ev_b[i]) (void)hipEventDestroy(p->ev_b[i]);
+  }
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
   void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW};
@@ -575,6 +620,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "wg_points") { if (!pow2(value) || value < 256 || value > 16384) return fail(CWT_EINVAL, "wg_points: power of two in [256,16384]"); p->log_wg_points = ilog2(value); }
   else if (k == "profile") p->profile = value != 0;
   else if (k == "ct") p->use_ct = value != 0;
+  else if (k == "overlap") p->overlap = value != 0;
   else return fail(CWT_EINVAL, "unknown option " + k);
   if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
   return CWT_OK;

@@ -250,7 +250,7 @@ k_narrow(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mot
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const long n = (long(g.j + (e << logNT)) << logR) + r;
-    if (n < ncols) wrow[n] = mk<T>(re[e], im[e]);
+    if (n < ncols) store_w<T>(wrow + n, re[e], im[e]);
   }
 }
 
@@ -351,7 +351,7 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const int idx = threadIdx.x + c * blockDim.x;
     const long m = idx >> logTB, t = idx & ((1 << logTB) - 1);
     const long n = (m << logR) + r0 + t;
-    if (n < ncols) wrow[n] = mk<T>(re[c], CONJ ? -im[c] : im[c]);
+    if (n < ncols) store_w<T>(wrow + n, re[c], CONJ ? -im[c] : im[c]);
   }
 }
 
@@ -407,7 +407,7 @@ k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const unsigned step_e = unsigned(e * NT) << logR;
-    if (long(off) + step_e < ncols) (wrow + step_e)[off] = mk<T>(re[e], im[e]);
+    if (long(off) + step_e < ncols) store_w<T>(wrow + step_e + off, re[e], im[e]);
   }
 }
 
@@ -504,7 +504,7 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const unsigned step_c = unsigned(c * (BD >> LOGTB)) << logR;
-    if (long(off) + step_c < ncols) (wrow + step_c)[off] = mk<T>(re[c], CONJ ? -im[c] : im[c]);
+    if (long(off) + step_c < ncols) store_w<T>(wrow + step_c + off, re[c], CONJ ? -im[c] : im[c]);
   }
 }
 
