@@ -171,9 +171,17 @@ def main():
     achieved = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
     gpu_ms = sum(v["ms_per_step"] for v in kern.values())
     alg_bytes_total = units_per_step / world * csize + N * (csize // 2)
+    traffic = None                      # HBM bytes per launch of the dominant kernel, from committed PMC passes
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+    if os.path.exists(tpath) and not opts and args.logn == 20 and args.rows == 256:
+        t = json.load(open(tpath))["per_kernel_class"].get(dom)
+        if t:
+            traffic = t["hbm_bytes_per_launch"]
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "traffic_source": (f"profiles/traffic_{args.config}.json (rocprofv3 PMC passes of this command, "
+                           "FETCH_SIZE x2 + WRITE_SIZE)") if traffic else None,
         "avg_launch_ms": dom_avg_ms, "launches_per_step": dom_launches,
         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         "whole_path": {"algorithmic_bytes_per_step_per_gpu": alg_bytes_total,

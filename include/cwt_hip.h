@@ -68,7 +68,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "narrow_max_k" largest per-row transform length of that path (power of two)
  *   "lmax"         largest single-workgroup FFT length (power of two, <= 4096)
  *   "wg_points"    complex points per workgroup of the fused kernels
- *   "overlap"      0 = run the two passes of the wide rows strictly one after the other
+ *   "narrow_terms" largest number of aliased bins per FFT input of that path (1 = off)
+ *   "overlap"      1 = run pass A of chunk c+1 beside pass B of chunk c on side
+ *                  streams; 0 (default) = strictly one after the other
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);

@@ -65,7 +65,8 @@ struct cwt_plan {
   int log_wg_points = 13;
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
-  int overlap = 1;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
+  int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
@@ -85,7 +86,7 @@ struct cwt_plan {
   int last_mother = -1; double last_param = 0, last_dt = 0;
   bool table_valid = false;
   std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
-  struct Group { int logK; int first; int count; };
+  struct Group { int logK; int first; int count; bool multi; };
   std::vector<Group> narrow_groups;
   int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
   int split[3] = {0, 0, 0};
@@ -238,6 +239,9 @@ int build_row_table(cwt_plan* p, int mother, double param, double dt, const doub
   const int logP = std::min(p->log_wg_points, p->logN);
   const bool use_small = p->logN <= p->loglmax;
   const int narrow_cap = std::min(p->narrow_max_logk, logP - 1);
+  // the multi-term form exists only in the compile-time kernel for K = 1024 at the default geometry
+  const bool multi_ok = p->use_ct && p->narrow_terms > 1 && narrow_cap >= 10 &&
+                        logP == (p->prec == 64 ? 13 : 14);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
   for (int j = 0; j < nrows; ++j) {
     const double s = scales[j];
@@ -257,6 +261,7 @@ int build_row_table(cwt_plan* p, int mother, double param, double dt, const doub
     if (rd.nband == 0) rd.k_lo = 0;
     rd.out_row = j;
     rd.logK = 0;
+    rd.nterms = 1;
     if (use_small) {
       small_rows.push_back(rd);
     } else {
@@ -264,19 +269,26 @@ int build_row_table(cwt_plan* p, int mother, double param, double dt, const doub
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
+      } else if (p->narrow && multi_ok && rd.nband <= (p->narrow_terms << 10)) {
+        rd.logK = 10;                                   // several aliased bins per input (k_narrow_ct)
+        rd.nterms = (rd.nband + 1023) >> 10;
+        narrow_rows.push_back(rd);
       } else {
         wide_rows.push_back(rd);
       }
     }
   }
+  auto group_key = [](const RowDesc& x) { return x.logK + (x.nterms > 1 ? 100 : 0); };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
-                   [](const RowDesc& x, const RowDesc& y) { return x.logK < y.logK; });
+                   [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
   p->table.clear();
   p->narrow_groups.clear();
   p->table.insert(p->table.end(), small_rows.begin(), small_rows.end());
   for (size_t i = 0; i < narrow_rows.size(); ++i) {
-    if (p->narrow_groups.empty() || p->narrow_groups.back().logK != narrow_rows[i].logK)
-      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0});
+    const bool multi = narrow_rows[i].nterms > 1;
+    if (p->narrow_groups.empty() || p->narrow_groups.back().logK != narrow_rows[i].logK ||
+        p->narrow_groups.back().multi != multi)
+      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0, multi});
     p->narrow_groups.back().count++;
     p->table.push_back(narrow_rows[i]);
   }
@@ -309,11 +321,11 @@ int ensure_z(cwt_plan* p, int rows) {
 // ---- compile-time specialised kernels for the default geometry --------------------------------
 template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 : 14; }
 
-template <typename T, int LOGK>
+template <typename T, int LOGK, bool MULTI = false>
 void launch_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo,
                       cplx<T>* W, int64_t ldw, int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
-  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP>), dim3(1u << (p->logN - LOGP), g.count),
+  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP, MULTI>), dim3(1u << (p->logN - LOGP), g.count),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                      p->rows_dev + g.first, mo, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw),
                      long(ncols));
@@ -323,7 +335,7 @@ template <typename T>
 bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo, cplx<T>* W,
                    int64_t ldw, int64_t ncols) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  switch (g.logK) {
+  switch (g.logK + (g.multi ? 100 : 0)) {
     case 4: launch_narrow_ct<T, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 5: launch_narrow_ct<T, 5>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 6: launch_narrow_ct<T, 6>(p, g, xhat, mo, W, ldw, ncols); return true;
@@ -331,6 +343,7 @@ bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, c
     case 8: launch_narrow_ct<T, 8>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 9: launch_narrow_ct<T, 9>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 10: launch_narrow_ct<T, 10>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 110: launch_narrow_ct<T, 10, true>(p, g, xhat, mo, W, ldw, ncols); return true;   // 2..4 terms
     default: return false;
   }
 }
@@ -621,6 +634,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "profile") p->profile = value != 0;
   else if (k == "ct") p->use_ct = value != 0;
   else if (k == "overlap") p->overlap = value != 0;
+  else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
   return CWT_OK;

@@ -34,6 +34,7 @@ struct RowDesc {
   int nband;       // number of bins in the support; k_lo + nband - 1 <= N/2 - 1
   int out_row;     // destination row of W
   int logK;        // k_narrow: log2 of this row's FFT length
+  int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
 };
 
 struct Mother {
@@ -361,7 +362,7 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 // grids as the generic kernels above; the host picks them when the geometry matches.
 // Global accesses are written as (uniform pointer)[32-bit lane offset] so that they compile to
 // SGPR-base + VGPR-offset instructions instead of 64-bit per-lane address arithmetic.
-template <typename T, int LOGK, int LOGP>
+template <typename T, int LOGK, int LOGP, bool MULTI>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
             const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
@@ -377,30 +378,42 @@ k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
   f.j = threadIdx.x >> LOGTB;
   const unsigned r = (blockIdx.x << LOGTB) + f.t;
 
+  // Input of the K-point FFT for output residue r (n = R m + r):
+  //   Z_r[q] = sum_{i < nterms} Y[k_i(q)] e^{2 pi i k_i(q) r / N},  k_i(q) = k_lo + ((q - k_lo) mod K) + i K
+  // nterms = 1 for rows whose support fits K bins; 2..4 terms otherwise (MULTI, K = 1024 only), which
+  // still beats a two-pass transform because the row then needs no intermediate in memory.
+  // Per term: the Y tile (K complex) is built cooperatively in LDS, then every thread walks its 16
+  // inputs with a running twiddle that advances by e^{2 pi i NT r / N} per slot and by an extra
+  // e^{-2 pi i K r / N} where k_0(q) wraps around the band start.
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
-  for (int q = threadIdx.x; q < K; q += (1 << (LOGP - 4))) {
+  const unsigned nm = unsigned(N - 1);
+  const int nterms = MULTI ? rd.nterms : 1;            // <= 4: all tiles fit the 64 KiB LDS buffer
+  for (int idx = threadIdx.x; idx < (nterms << LOGK); idx += (1 << (LOGP - 4))) {
+    const int q = idx & (K - 1);
     const int d = (q - rd.k_lo) & (K - 1);
-    ytile[q] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d, N - 1);
+    ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d + (idx & ~(K - 1)), N - 1);
   }
   __syncthreads();
+  const cplx<T> step = twn((unsigned(NT) * r) & nm);
+  const cplx<T> stepw = cmul<T>(step, twn((0u - (r << LOGK)) & nm));
+  const int d0 = (f.j - rd.k_lo) & (K - 1);
   T re[16], im[16];
-  {
-    const unsigned nm = unsigned(N - 1);
-    int d = (f.j - rd.k_lo) & (K - 1);
-    cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
-    const cplx<T> step = twn((unsigned(NT) * r) & nm);
-    const cplx<T> stepw = cmul<T>(step, twn((0u - (r << LOGK)) & nm));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { re[e] = T(0); im[e] = T(0); }
+  for (int i = 0; i < nterms; ++i) {
+    int d = d0;
+    cplx<T> cur = twn((unsigned(rd.k_lo + d + (i << LOGK)) * r) & nm);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const cplx<T> y = ytile[f.j + e * NT];
-      re[e] = y.x * cur.x - y.y * cur.y;
-      im[e] = y.x * cur.y + y.y * cur.x;
+      const cplx<T> y = ytile[(i << LOGK) + f.j + e * NT];
+      re[e] += y.x * cur.x - y.y * cur.y;
+      im[e] += y.x * cur.y + y.y * cur.x;
       const int dn = (d + NT) & (K - 1);
       cur = cmul<T>(cur, dn < d ? stepw : step);
       d = dn;
     }
   }
-  __syncthreads();
+  __syncthreads();  // the tiles alias the exchange buffer
   f.run(re, im, lds, tw);
   cplx<T>* wrow = W + long(rd.out_row) * ldw;
   const unsigned off = (unsigned(f.j) << logR) + r;

@@ -1,0 +1,129 @@
+"""Scale-sharded CWT across the GPUs of one node (one process per GPU, torch.distributed).
+
+The rows (scales) of W are independent once the signal is known (pycwt/wavelet.py:102-106 is an
+outer product followed by independent inverse FFTs), so the only exchange of the path is ONE
+broadcast per transform: rank 0 owns the signal and broadcasts it (8 MiB at N = 2^20 fp64; backend
+"nccl" = RCCL over xGMI); every rank then runs the forward FFT itself (1/rows of its work, cheaper
+than moving the 16 MiB spectrum) and computes rows j = rank, rank + G, rank + 2G, ... into a
+device-resident shard.  Interleaving balances the load because small scales (two-pass rows) cost
+more than large ones.  W is never gathered (4 GiB would dwarf the compute); `icwt_sharded` reduces
+per-rank partial column sums with one `reduce`.
+
+torch is plumbing here: device memory, the current stream and the process group.  The compute goes
+through the C ABI (`_hip.Plan`) via `HipEngine`; tests substitute a CPU engine to exercise the
+sharding / collective logic under the gloo backend.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _hip
+from .wavelet import _check_parameter_wavelet, _device_id, _nan_rows, _next_pow2
+
+
+def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
+    """Indices of the rows owned by `rank` (interleaved)."""
+    return np.arange(rank, nrows, world)
+
+
+class HipEngine:
+    """Runs the hot path on this rank's GPU through libcwt_hip.so on torch's current stream."""
+
+    def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int):
+        import torch
+        self.torch = torch
+        self.plan = _hip.Plan(nfft, precision, max_rows=max_rows, device=device_index)
+        self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
+
+    def forward(self, x, n0, xhat):
+        self.plan.forward_fft(x.data_ptr(), n0, xhat.data_ptr())
+
+    def rows(self, xhat, kind, param, dt, sj, W, ncols):
+        self.plan.transform_rows(xhat.data_ptr(), kind, param, dt, sj, W.data_ptr(), W.shape[1], ncols)
+
+    def icwt_partial(self, W, sj, out):
+        self.plan.icwt_reduce(W.data_ptr(), W.shape[1], W.shape[1], sj, 1.0, out.data_ptr())
+
+
+def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, group=None,
+                precision=64, device=None, engine=None, src=0):
+    """Scale-sharded `cwt`.  Call on every rank of `group`; only rank `src` needs `signal`.
+
+    Returns `(W_local, rows_local, sj, freqs, coi)`: `W_local` is a device tensor
+    (len(rows_local) x n0, complex) holding rows `rows_local` of the full transform; `sj`, `freqs`,
+    `coi` describe the full transform exactly as `pycwt.cwt` returns them (after the Paul NaN-row
+    rule).  One broadcast of the signal, no other collective.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mother = _check_parameter_wavelet(wavelet)
+    real_t = torch.float64 if precision == 64 else torch.float32
+    cplx_t = torch.complex128 if precision == 64 else torch.complex64
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    meta = [len(signal) if rank == src else None]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=src, group=group)
+    n0 = int(meta[0])
+    x = torch.empty(n0, dtype=real_t, device=device)
+    if rank == src:
+        x.copy_(torch.as_tensor(np.asarray(signal), dtype=real_t))
+    if world > 1:
+        dist.broadcast(x, src=src, group=group)            # the one exchange of the path
+
+    # host scalars exactly as wavelet.py:75-88 / :111-115 / :120-121
+    if freqs is None:
+        if s0 == -1:
+            s0 = 2 * dt / mother.flambda()
+        if J == -1:
+            J = int(np.round(np.log2(n0 * dt / s0) / dj))
+        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+        freqs = 1 / (mother.flambda() * sj)
+    else:
+        sj = 1 / (mother.flambda() * freqs)
+    sj = np.asarray(sj, dtype=np.float64)
+    N = _next_pow2(n0)
+    bad = _nan_rows(mother, sj, N, dt)
+    if bad.any() and not bad.all():
+        sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
+    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+
+    mine = shard_rows(sj.size, world, rank)
+    kind, param = _device_id(mother)
+    if engine is None:
+        engine = HipEngine(N, precision, max(1, mine.size), device.index or 0)
+    xhat = torch.empty(N, dtype=cplx_t, device=device)
+    W = torch.empty((mine.size, n0), dtype=cplx_t, device=device)
+    engine.forward(x, n0, xhat)
+    if mine.size:
+        engine.rows(xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+    return W, mine, sj, freqs, coi
+
+
+def icwt_sharded(W_local, sj_local, dt, dj=1 / 12, wavelet="morlet", *, group=None, engine=None, dst=0):
+    """TC98 eq. 11 over row shards: per-rank partial sums, one `reduce` to rank `dst`.
+
+    Returns the reconstruction on rank `dst` (NumPy, dtype as `pycwt.icwt`), None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    mother = _check_parameter_wavelet(wavelet)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    real_t = torch.float64 if W_local.dtype == torch.complex128 else torch.float32
+    part = torch.zeros(W_local.shape[1], dtype=real_t, device=W_local.device)
+    if W_local.shape[0]:
+        if engine is None:
+            raise ValueError("pass the engine used by cwt_sharded (it owns the device plan)")
+        engine.icwt_partial(W_local, np.ascontiguousarray(sj_local, dtype=np.float64), part)
+    if world > 1:
+        dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if rank != dst:
+        return None
+    total = part.cpu().numpy().astype(np.float64)
+    return dj * np.sqrt(dt) / (mother.cdelta * mother.psi(0)) * total

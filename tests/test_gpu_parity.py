@@ -191,3 +191,17 @@ def test_edge_cases(hip_library):
     Wr = orc.cwt_rows(x, 1.0, 1 / (orc.Mother(orc.DOG, 2).flambda() * np.array([1e-9, 0.2])),
                       orc.Mother(orc.DOG, 2))[:, :4097]
     assert W.shape == (2, 4097) and np.abs(W - Wr).max() < 1e-9
+
+
+def test_sharded_api_single_rank_matches_cwt(hip_library):
+    """parallel.cwt_sharded without a process group (1 GPU): device-resident shard == full transform."""
+    import torch
+    from pycwt_amd import parallel
+    x = np.random.default_rng(8).standard_normal(3000)
+    W, mine, sj, freqs, coi = parallel.cwt_sharded(x, 0.5, 0.25, wavelet="dog")
+    ref = pycwt_amd.cwt(x, 0.5, 0.25, wavelet="dog")
+    assert list(mine) == list(range(len(sj))) and W.is_cuda
+    per_row, _ = row_errors(W.cpu().numpy(), ref[0])
+    assert per_row.max() < 1e-12
+    np.testing.assert_allclose(sj, ref[1])
+    np.testing.assert_allclose(coi, ref[3])

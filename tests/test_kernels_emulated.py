@@ -70,8 +70,17 @@ def test_two_pass_and_band_limited_paths_small_geometry(emu_library, opts, kind,
 
 
 def test_default_geometry_two_pass_8192(emu_library):
-    split = run_case(emu_library, 8192, 8000, orc.MORLET, 6, 16)
+    split = run_case(emu_library, 8192, 8000, orc.MORLET, 6, 16, opts={"narrow_terms": 1})
     assert split["narrow"] > 0 and split["two_pass"] > 0
+
+
+@pytest.mark.parametrize("terms", [2, 3, 4])
+@pytest.mark.parametrize("kind,param", [(orc.MORLET, 6), (orc.PAUL, 4), (orc.DOG, 2)])
+def test_band_limited_rows_with_several_aliased_terms(emu_library, terms, kind, param):
+    """Supports wider than K = 1024 bins handled in one pass (compile-time kernels, default geometry)."""
+    one = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": 1})
+    many = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": terms})
+    assert many["narrow"] > one["narrow"]
 
 
 def test_default_geometry_fp32(emu_library):

@@ -1,0 +1,92 @@
+"""Multi-process path of pycwt_amd.parallel under the gloo backend (world_size 2, CPU).
+
+The collective logic (one broadcast of the signal, interleaved row shards, one reduce for icwt) is
+exercised for real; the per-rank compute engine is a CPU stand-in built on the oracle, injected
+through the `engine=` test hook (the product default is the HIP engine)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class OracleEngine:
+    """CPU engine with the interface of parallel.HipEngine (test infrastructure)."""
+
+    def __init__(self):
+        from oracle import cwt_oracle as orc
+        self.orc = orc
+        self.calls = []
+
+    def forward(self, x, n0, xhat):
+        self.calls.append("forward")
+        xhat.copy_(torch.from_numpy(np.fft.fft(x.numpy(), n=xhat.numel())))
+        self.x = x.numpy().copy()
+
+    def rows(self, xhat, kind, param, dt, sj, W, ncols):
+        self.calls.append(("rows", len(sj)))
+        m = self.orc.Mother(kind, int(param) if kind else param)
+        W.copy_(torch.from_numpy(self.orc.cwt_rows(self.x, dt, sj, m)[:, :ncols]))
+
+    def icwt_partial(self, W, sj, out):
+        out.copy_(torch.from_numpy((W.numpy().real / np.sqrt(sj)[:, None]).sum(axis=0)))
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pycwt_amd import parallel
+    x = np.random.default_rng(4).standard_normal(777) if rank == 0 else None    # only rank 0 has the signal
+    eng = OracleEngine()
+    W, mine, sj, freqs, coi = parallel.cwt_sharded(x, 0.3, 1 / 6, -1, -1, "paul", engine=eng,
+                                                   device=torch.device("cpu"))
+    assert eng.calls[0] == "forward" and eng.calls[1] == ("rows", len(mine))
+    iw = parallel.icwt_sharded(W, sj[mine], 0.3, 1 / 6, "paul", engine=eng)
+    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), W=W.numpy(), mine=mine, sj=sj, freqs=freqs, coi=coi,
+             iw=np.zeros(0) if iw is None else iw)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_broadcast_and_reduce(tmp_path):
+    from oracle import cwt_oracle as orc
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    x = np.random.default_rng(4).standard_normal(777)
+    W, sj, freqs, coi, _, _ = orc.cwt(x, 0.3, 1 / 6, -1, -1, "paul")
+    assert list(r0["mine"]) == list(range(0, len(sj), 2)) and list(r1["mine"]) == list(range(1, len(sj), 2))
+    full = np.empty_like(W)
+    full[r0["mine"]] = r0["W"]
+    full[r1["mine"]] = r1["W"]
+    np.testing.assert_allclose(full, W, rtol=1e-12, atol=1e-13)        # rank 1 got the signal by broadcast
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["sj"], sj)
+        np.testing.assert_allclose(r["coi"], coi)
+    np.testing.assert_allclose(r0["iw"], orc.icwt(W, sj, 0.3, 1 / 6, "paul"), rtol=1e-11, atol=1e-13)
+    assert r1["iw"].size == 0
+
+
+def test_shard_rows_partition():
+    from pycwt_amd.parallel import shard_rows
+    for n in (1, 7, 256):
+        for world in (1, 2, 4, 8):
+            parts = [shard_rows(n, world, r) for r in range(world)]
+            assert sorted(np.concatenate(parts)) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OU
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o cwt -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o cwt -- $BENCH > $OUT/pmc_tcc.log 2>&1
 find $OUT -name "*.csv" | head -30
-python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python tools/summarize_prof.py $OUT --traffic-json $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small files
 find $OUT -type f -size +8M -delete

@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 csv output (kernel stats + PMC passes) per kernel name."""
+"""Summarise rocprofv3 csv output (kernel stats + PMC passes) per kernel name.
+
+usage: summarize_prof.py <dir> [--traffic-json out.json]
+PMC corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are collected in separate passes, are reported in KiB, and FETCH_SIZE counts a wide
+coalesced read at half its bytes on gfx950 (so it is doubled here).
+"""
 import csv
 import glob
+import json
 import os
 import re
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+traffic_out = sys.argv[sys.argv.index("--traffic-json") + 1] if "--traffic-json" in sys.argv else None
 
 
 def short(name):
@@ -15,12 +23,23 @@ def short(name):
     return name.replace("void cwt::", "").replace("cwt::", "")[:60]
 
 
+def klass(name):
+    for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
+        if name.startswith(k):
+            fwd = name.rstrip(">").endswith(", 1") or name.rstrip(">").endswith("true")
+            return ("fwd_" if fwd and k in ("k_pass_a", "k_pass_b") else "") + k[2:]
+    return None
+
+
+stats = {}
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats", os.path.relpath(f, root))
     for row in csv.DictReader(open(f)):
         print(f"{short(row['Name']):60s} calls {row['Calls']:>6s} total_ns {row['TotalDurationNs']:>12s} "
               f"avg_ns {float(row['AverageNs']):12.1f} pct {row['Percentage']}")
+        stats[short(row["Name"])] = (int(row["Calls"]), float(row["TotalDurationNs"]))
 
+pmc = defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -40,3 +59,32 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         vals = "  ".join(f"{c}={agg[k][c] / cnt[k][c]:.4g}" for c in sorted(agg[k]))
         n = max(cnt[k].values())
         print(f"{k:60s} n={n:5d}  {vals}")
+        for c in agg[k]:
+            pmc[k][c] = (agg[k][c], cnt[k][c])
+
+if traffic_out:
+    per_class = defaultdict(lambda: {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0, "ns": 0.0, "calls": 0})
+    for k, counters in pmc.items():
+        c = klass(k)
+        if not c:
+            continue
+        if "FETCH_SIZE" in counters:
+            per_class[c]["fetch_bytes"] += 2.0 * 1024.0 * counters["FETCH_SIZE"][0]
+            per_class[c]["launches"] += counters["FETCH_SIZE"][1]
+        if "WRITE_SIZE" in counters:
+            per_class[c]["write_bytes"] += 1024.0 * counters["WRITE_SIZE"][0]
+    for k, (calls, ns) in stats.items():
+        c = klass(k)
+        if c:
+            per_class[c]["ns"] += ns
+            per_class[c]["calls"] += calls
+    out = {}
+    for c, v in per_class.items():
+        n = max(v["launches"], 1)
+        out[c] = {"hbm_bytes_per_launch": (v["fetch_bytes"] + v["write_bytes"]) / n,
+                  "fetch_bytes_per_launch": v["fetch_bytes"] / n, "write_bytes_per_launch": v["write_bytes"] / n,
+                  "launches_profiled": v["launches"],
+                  "avg_launch_ns_rocprof": v["ns"] / max(v["calls"], 1)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB units",
+               "per_kernel_class": out}, open(traffic_out, "w"), indent=1)
+    print("wrote", traffic_out)
