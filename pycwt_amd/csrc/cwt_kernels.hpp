@@ -471,7 +471,7 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
 }
 
 template <typename T, int LOGK, int LOGP, bool CONJ>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 4 : 8))
 k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
             const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
