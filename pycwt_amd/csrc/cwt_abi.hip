@@ -86,7 +86,7 @@ struct cwt_plan {
   int last_mother = -1; double last_param = 0, last_dt = 0;
   bool table_valid = false;
   std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
-  struct Group { int logK; int first; int count; bool multi; };
+  struct Group { int logK; int first; int count; int nterms; };
   std::vector<Group> narrow_groups;
   int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
   int split[3] = {0, 0, 0};
@@ -278,17 +278,17 @@ int build_row_table(cwt_plan* p, int mother, double param, double dt, const doub
       }
     }
   }
-  auto group_key = [](const RowDesc& x) { return x.logK + (x.nterms > 1 ? 100 : 0); };
+  auto group_key = [](const RowDesc& x) { return x.logK + 100 * x.nterms; };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
   p->table.clear();
   p->narrow_groups.clear();
   p->table.insert(p->table.end(), small_rows.begin(), small_rows.end());
   for (size_t i = 0; i < narrow_rows.size(); ++i) {
-    const bool multi = narrow_rows[i].nterms > 1;
+    const int nt = narrow_rows[i].nterms;
     if (p->narrow_groups.empty() || p->narrow_groups.back().logK != narrow_rows[i].logK ||
-        p->narrow_groups.back().multi != multi)
-      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0, multi});
+        p->narrow_groups.back().nterms != nt)
+      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0, nt});
     p->narrow_groups.back().count++;
     p->table.push_back(narrow_rows[i]);
   }
@@ -321,11 +321,11 @@ int ensure_z(cwt_plan* p, int rows) {
 // ---- compile-time specialised kernels for the default geometry --------------------------------
 template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 : 14; }
 
-template <typename T, int LOGK, bool MULTI = false>
+template <typename T, int LOGK, int NTERMS = 1>
 void launch_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo,
                       cplx<T>* W, int64_t ldw, int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
-  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP, MULTI>), dim3(1u << (p->logN - LOGP), g.count),
+  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP, NTERMS>), dim3(1u << (p->logN - LOGP), g.count),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                      p->rows_dev + g.first, mo, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw),
                      long(ncols));
@@ -335,7 +335,7 @@ template <typename T>
 bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo, cplx<T>* W,
                    int64_t ldw, int64_t ncols) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  switch (g.logK + (g.multi ? 100 : 0)) {
+  switch (g.logK + (g.nterms > 1 ? 100 * g.nterms : 0)) {
     case 4: launch_narrow_ct<T, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 5: launch_narrow_ct<T, 5>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 6: launch_narrow_ct<T, 6>(p, g, xhat, mo, W, ldw, ncols); return true;
@@ -343,7 +343,9 @@ bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, c
     case 8: launch_narrow_ct<T, 8>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 9: launch_narrow_ct<T, 9>(p, g, xhat, mo, W, ldw, ncols); return true;
     case 10: launch_narrow_ct<T, 10>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 110: launch_narrow_ct<T, 10, true>(p, g, xhat, mo, W, ldw, ncols); return true;   // 2..4 terms
+    case 210: launch_narrow_ct<T, 10, 2>(p, g, xhat, mo, W, ldw, ncols); return true;   // 2..4 aliased terms
+    case 310: launch_narrow_ct<T, 10, 3>(p, g, xhat, mo, W, ldw, ncols); return true;
+    case 410: launch_narrow_ct<T, 10, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
     default: return false;
   }
 }

@@ -362,7 +362,7 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 // grids as the generic kernels above; the host picks them when the geometry matches.
 // Global accesses are written as (uniform pointer)[32-bit lane offset] so that they compile to
 // SGPR-base + VGPR-offset instructions instead of 64-bit per-lane address arithmetic.
-template <typename T, int LOGK, int LOGP, bool MULTI>
+template <typename T, int LOGK, int LOGP, int NTERMS>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
             const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
@@ -380,38 +380,40 @@ k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
 
   // Input of the K-point FFT for output residue r (n = R m + r):
   //   Z_r[q] = sum_{i < nterms} Y[k_i(q)] e^{2 pi i k_i(q) r / N},  k_i(q) = k_lo + ((q - k_lo) mod K) + i K
-  // nterms = 1 for rows whose support fits K bins; 2..4 terms otherwise (MULTI, K = 1024 only), which
+  // NTERMS = 1 for rows whose support fits K bins; 2..4 terms otherwise (K = 1024 only), which
   // still beats a two-pass transform because the row then needs no intermediate in memory.
   // Per term: the Y tile (K complex) is built cooperatively in LDS, then every thread walks its 16
   // inputs with a running twiddle that advances by e^{2 pi i NT r / N} per slot and by an extra
   // e^{-2 pi i K r / N} where k_0(q) wraps around the band start.
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
   const unsigned nm = unsigned(N - 1);
-  const int nterms = MULTI ? rd.nterms : 1;            // <= 4: all tiles fit the 64 KiB LDS buffer
-  for (int idx = threadIdx.x; idx < (nterms << LOGK); idx += (1 << (LOGP - 4))) {
+  for (int idx = threadIdx.x; idx < (NTERMS << LOGK); idx += (1 << (LOGP - 4))) {
     const int q = idx & (K - 1);
     const int d = (q - rd.k_lo) & (K - 1);
     ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d + (idx & ~(K - 1)), N - 1);
   }
   __syncthreads();
+  // Z_r[q] = e^{2 pi i k_0(q) r / N} * sum_i Y_i[q] rho^i (Horner), rho = e^{2 pi i K r / N}; the common
+  // factor is a running product over the 16 slots that picks up rho^-1 where k_0(q) wraps
   const cplx<T> step = twn((unsigned(NT) * r) & nm);
-  const cplx<T> stepw = cmul<T>(step, twn((0u - (r << LOGK)) & nm));
-  const int d0 = (f.j - rd.k_lo) & (K - 1);
+  const cplx<T> rho = twn((r << LOGK) & nm);
+  const cplx<T> stepw = cmul<T>(step, mk<T>(rho.x, -rho.y));
+  int d = (f.j - rd.k_lo) & (K - 1);
+  cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
   T re[16], im[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { re[e] = T(0); im[e] = T(0); }
-  for (int i = 0; i < nterms; ++i) {
-    int d = d0;
-    cplx<T> cur = twn((unsigned(rd.k_lo + d + (i << LOGK)) * r) & nm);
+  for (int e = 0; e < 16; ++e) {
+    cplx<T> h = ytile[((NTERMS - 1) << LOGK) + f.j + e * NT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int i = NTERMS - 2; i >= 0; --i) {
       const cplx<T> y = ytile[(i << LOGK) + f.j + e * NT];
-      re[e] += y.x * cur.x - y.y * cur.y;
-      im[e] += y.x * cur.y + y.y * cur.x;
-      const int dn = (d + NT) & (K - 1);
-      cur = cmul<T>(cur, dn < d ? stepw : step);
-      d = dn;
+      h = mk<T>(h.x * rho.x - h.y * rho.y + y.x, h.x * rho.y + h.y * rho.x + y.y);
     }
+    re[e] = h.x * cur.x - h.y * cur.y;
+    im[e] = h.x * cur.y + h.y * cur.x;
+    const int dn = (d + NT) & (K - 1);
+    cur = cmul<T>(cur, dn < d ? stepw : step);
+    d = dn;
   }
   __syncthreads();  // the tiles alias the exchange buffer
   f.run(re, im, lds, tw);

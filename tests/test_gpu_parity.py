@@ -205,3 +205,27 @@ def test_sharded_api_single_rank_matches_cwt(hip_library):
     assert per_row.max() < 1e-12
     np.testing.assert_allclose(sj, ref[1])
     np.testing.assert_allclose(coi, ref[3])
+
+
+@pytest.mark.parametrize("logn,prec,rows", [(21, 64, 6), (22, 64, 5), (23, 32, 4), (24, 32, 3), (24, 64, 2)])
+def test_long_series_up_to_the_plan_limit(hip_library, logn, prec, rows):
+    """N = 2^21 .. 2^24 (the two-pass limit lmax^2): column FFTs of 2048..4096 points, generic engine."""
+    N = 1 << logn
+    x = np.random.default_rng(logn).standard_normal(N - 7)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, rows)
+    plan = _hip.Plan(N, prec, max_rows=8)
+    W, xhat = plan.execute_host(x, orc.MORLET, 6, 1.0, sj)
+    plan.close()
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size]
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < TOL[prec], per_row
+    xref = np.fft.fft(x, n=N)
+    assert np.abs(xhat - xref).max() / np.abs(xref).max() < TOL[prec]
+
+
+def test_plan_rejects_lengths_beyond_limit(hip_library):
+    with pytest.raises(_hip.HipError, match="power of two"):
+        _hip.Plan(1 << 25, 64, max_rows=1)
+    with pytest.raises(_hip.HipError, match="power of two"):
+        _hip.Plan(3000, 64, max_rows=1)
