@@ -321,33 +321,19 @@ int ensure_z(cwt_plan* p, int rows) {
 // ---- compile-time specialised kernels for the default geometry --------------------------------
 template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 : 14; }
 
-template <typename T, int LOGK, int NTERMS = 1>
-void launch_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo,
-                      cplx<T>* W, int64_t ldw, int64_t ncols) {
-  constexpr int LOGP = default_logp<T>();
-  hipLaunchKernelGGL((k_narrow_ct<T, LOGK, LOGP, NTERMS>), dim3(1u << (p->logN - LOGP), g.count),
-                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
-                     p->rows_dev + g.first, mo, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw),
-                     long(ncols));
-}
-
+// all band-limited rows in one launch (k_narrow_ct_all); false if the geometry is not the default one
 template <typename T>
-bool try_narrow_ct(cwt_plan* p, const cwt_plan::Group& g, const cplx<T>* xhat, const Mother& mo, cplx<T>* W,
-                   int64_t ldw, int64_t ncols) {
-  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  switch (g.logK + (g.nterms > 1 ? 100 * g.nterms : 0)) {
-    case 4: launch_narrow_ct<T, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 5: launch_narrow_ct<T, 5>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 6: launch_narrow_ct<T, 6>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 7: launch_narrow_ct<T, 7>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 8: launch_narrow_ct<T, 8>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 9: launch_narrow_ct<T, 9>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 10: launch_narrow_ct<T, 10>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 210: launch_narrow_ct<T, 10, 2>(p, g, xhat, mo, W, ldw, ncols); return true;   // 2..4 aliased terms
-    case 310: launch_narrow_ct<T, 10, 3>(p, g, xhat, mo, W, ldw, ncols); return true;
-    case 410: launch_narrow_ct<T, 10, 4>(p, g, xhat, mo, W, ldw, ncols); return true;
-    default: return false;
-  }
+bool try_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
+                       int64_t ncols) {
+  constexpr int LOGP = default_logp<T>();
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != LOGP) return false;
+  for (const auto& g : p->narrow_groups)
+    if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 4 || (g.nterms > 1 && g.logK != 10)) return false;
+  hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), p->n_narrow),
+                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
+                     p->rows_dev + p->narrow_groups.front().first, mo, static_cast<const cplx<T>*>(p->tw_all),
+                     twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
+  return true;
 }
 
 template <typename T, int LOGR, int MODE>
@@ -494,15 +480,21 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
   }
-  // band-limited rows go to the plan's own stream and overlap with the two-pass pipeline
-  for (const auto& g : p->narrow_groups) {
-    rc = timed_launch(p, KC_NARROW, [&] {
-      if (try_narrow_ct<T>(p, g, xhat, mo, W, ldw, ncols)) return;
-      hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
-                         xhat, p->rows_dev + g.first, mo, tw_table<T>(p, g.logK), twn_of<T>(p), logN,
-                         g.logK, logP - g.logK, W, long(ldw), long(ncols));
-    });
+  // band-limited rows go to the plan's own stream
+  if (p->n_narrow) {
+    bool done = false;
+    rc = timed_launch(p, KC_NARROW, [&] { done = try_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
     if (rc) return rc;
+    if (!done) {
+      for (const auto& g : p->narrow_groups) {
+        rc = timed_launch(p, KC_NARROW, [&] {
+          hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
+                             xhat, p->rows_dev + g.first, mo, tw_table<T>(p, g.logK), twn_of<T>(p), logN,
+                             g.logK, logP - g.logK, W, long(ldw), long(ncols));
+        });
+        if (rc) return rc;
+      }
+    }
   }
   if (p->n_wide) {
     const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));

@@ -363,16 +363,14 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 // Global accesses are written as (uniform pointer)[32-bit lane offset] so that they compile to
 // SGPR-base + VGPR-offset instructions instead of 64-bit per-lane address arithmetic.
 template <typename T, int LOGK, int LOGP, int NTERMS>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
-k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
-            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
-            long ncols) {
-  HIP_DYNAMIC_SHARED(double2, lds_raw)
-  T* lds = reinterpret_cast<T*>(lds_raw);
+__device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
+                                               const Mother& mo, const cplx<T>* __restrict__ tw_all,
+                                               const TwN<T>& twn, int logN, cplx<T>* __restrict__ W, long ldw,
+                                               long ncols, T* lds) {
   constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
   using F = ct::Fft<T, LOGK, LOGTB, true>;
   const int N = 1 << logN, logR = logN - LOGK;
-  const RowDesc rd = rows[blockIdx.y];
+  const cplx<T>* tw = tw_all + (K - 2);                 // table of e^{2 pi i p / K}
   F f;
   f.t = threadIdx.x & ((1 << LOGTB) - 1);
   f.j = threadIdx.x >> LOGTB;
@@ -424,6 +422,30 @@ k_narrow_ct(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
     const unsigned step_e = unsigned(e * NT) << logR;
     if (long(off) + step_e < ncols) store_w<T>(wrow + step_e + off, re[e], im[e]);
   }
+}
+
+// All band-limited rows of a transform in ONE launch: blockIdx.y walks the row table (sorted by
+// class), every workgroup branches once to the body specialised for its row's (K, terms).  One
+// launch instead of one per class removes ~10 kernel boundaries and partial last waves per transform.
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+                const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
+                long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+#define CWT_NARROW_CASE(LK, NT_)                                                                    \
+  case (LK) + 100 * (NT_):                                                                           \
+    narrow_ct_body<T, LK, LOGP, NT_>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds);          \
+    break;
+  switch (rd.logK + 100 * rd.nterms) {
+    CWT_NARROW_CASE(4, 1) CWT_NARROW_CASE(5, 1) CWT_NARROW_CASE(6, 1) CWT_NARROW_CASE(7, 1)
+    CWT_NARROW_CASE(8, 1) CWT_NARROW_CASE(9, 1) CWT_NARROW_CASE(10, 1) CWT_NARROW_CASE(10, 2)
+    CWT_NARROW_CASE(10, 3) CWT_NARROW_CASE(10, 4)
+    default: break;
+  }
+#undef CWT_NARROW_CASE
 }
 
 template <typename T, int LOGR, int LOGP, int MODE>
