@@ -103,6 +103,41 @@ int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double 
                        const double* scales_host, int nrows, void* W_dev, int64_t ldw,
                        int64_t ncols);
 
+/* ---- building blocks of the callers of cwt (next rows of the hot-path table: Morlet.smooth,
+ * xwt, wct).  All device resident, queued on the plan's stream.
+ *
+ * Forward FFT of every row of a matrix, zero padded from ncols_in to nfft:
+ *   spec[r, k] = sum_n in[r, n] exp(-2*pi*i*k*n/nfft)
+ * replaces `fft.fft(W, axis=1, **fft_kwargs(W[0, :]))` of Morlet.smooth, mothers.py:90.
+ * in_dev: nrows x in_ld reals (in_complex = 0) or complex (in_complex = 1); spec_dev: nrows x nfft. */
+int cwt_fft_rows(cwt_plan* plan, const void* in_dev, int in_complex, int nrows, int64_t in_ld,
+                 int64_t ncols_in, void* spec_dev);
+
+/* Generalised cwt_transform_rows: every row has its own spectrum, profile scale and amplitude:
+ *   W[j, n] = (1/nfft) sum_k spec[j*spec_ld + k] * amp_j * profile(a_j * sk) * exp(+2*pi*i*k*n/nfft),
+ * sk = signed bin index of k (k - nfft for k >= nfft/2), profile = the real profile of `mother`
+ * (exp(-(f-f0)^2/2) | f^m exp(-f) [f>0] | f^m exp(-f^2/2)).  spec_ld = 0 shares one spectrum.
+ * With mother = CWT_DOG, param = 0, a_j = (s_j/dt)*2*pi/nfft, amp = 1 this is the time smoothing
+ * `ifft(F * fft(W))`, F = exp(-0.5*(s/dt)^2*k^2), of mothers.py:83-93.                            */
+int cwt_filter_rows(cwt_plan* plan, const void* spec_dev, int64_t spec_ld, int mother, double param,
+                    const double* a_host, const double* amp_re_host, const double* amp_im_host,
+                    int nrows, void* W_dev, int64_t ldw, int64_t ncols);
+
+/* Boxcar along the scale axis, = scipy.signal.convolve2d(T, win[:, None], 'same') with zero
+ * boundary (mothers.py:100-102).  in/out: nrows x ld complex, distinct buffers.                    */
+int cwt_boxcar_scales(cwt_plan* plan, const void* in_dev, int nrows, int64_t ld, int64_t ncols,
+                      const double* win_host, int nwin, void* out_dev);
+
+/* Element-wise inputs of the coherence (wavelet.py:503-514), all nrows x ld:
+ *   P = (|W1|^2 + i*|W2|^2)/s   (the two auto-spectra packed into one complex matrix: the smoothing
+ *                                kernel is real, so one smoothing pass serves both)
+ *   C = W1*conj(W2)/s ,  angle = arg(W1*conj(W2))  (reals)                                         */
+int cwt_wct_products(cwt_plan* plan, const void* W1_dev, const void* W2_dev, const double* scales_host,
+                     int nrows, int64_t ld, int64_t ncols, void* P_dev, void* C_dev, void* angle_dev);
+/* WCT = |S12|^2 / (S1*S2) with S = S1 + i*S2 (wavelet.py:513); out: nrows x ld reals.               */
+int cwt_wct_coherence(cwt_plan* plan, const void* S_dev, const void* S12_dev, int nrows, int64_t ld,
+                      int64_t ncols, void* out_dev);
+
 /* Inverse transform, TC98 eq. 11 (wavelet.py:169-170):
  *   out[n] = coeff * sum_j Re(W[j, n]) / sqrt(scales[j]),   n < ncols
  * coeff = dj*sqrt(dt)/(cdelta*psi(0)) is applied by the caller's real part; the

@@ -121,7 +121,45 @@ def big():
              rowsum=W.sum(axis=1), rowl2=np.sqrt((np.abs(W) ** 2).sum(axis=1)))
 
 
+def callers():
+    """Fixtures for the callers of the hot path: significance, xwt, Morlet.smooth, wct (sig=False)."""
+    import pycwt.helpers as rh
+    rng = np.random.default_rng(21)
+    n = 300
+    e1, e2 = rng.standard_normal(n), rng.standard_normal(n)
+    y1, y2 = np.zeros(n), np.zeros(n)
+    for i in range(1, n):                          # two correlated AR(1) series with a common 16-sample cycle
+        y1[i] = 0.6 * y1[i - 1] + e1[i]
+        y2[i] = 0.4 * y2[i - 1] + 0.5 * e1[i] + e2[i]
+    y1 += 2 * np.sin(2 * np.pi * np.arange(n) / 16.0)
+    y2 += 1.5 * np.sin(2 * np.pi * np.arange(n) / 16.0 + 1.0)
+    dt, dj = 0.5, 1 / 6
+    m = ref.Morlet(6)
+    W, sj, freqs, coi, _, _ = ref.cwt(y1, dt, dj, -1, -1, m)
+    out = dict(y1=y1, y2=y2, dt=dt, dj=dj, sj=sj,
+               ar1_y1=np.array(rh.ar1(y1)), ar1_y2=np.array(rh.ar1(y2)),
+               ar1_spec=rh.ar1_spectrum(freqs * dt, 0.55), rect7=rh.rect(7, normalize=True), rect1=rh.rect(1, True))
+    s0, f0 = ref.significance(y1, dt, sj, 0, None, 0.95, -1, m)
+    out.update(sig0=s0, fft0=f0)
+    dof = y1.size - sj                                # as sample/simple_sample.py:79-81
+    s1, f1 = ref.significance(y1.std() ** 2, dt, sj, 1, 0.6, 0.95, dof, m)
+    out.update(sig1=s1, fft1=f1)
+    s2, f2 = ref.significance(y1.std() ** 2, dt, sj, 2, 0.6, 0.95, [2, 8], m)
+    out.update(sig2=np.atleast_1d(s2), fft2=np.atleast_1d(f2))
+    W12, xcoi, xfreq, xsig = ref.xwt(y1, y2, dt, dj, -1, -1, 0.95, m, True)
+    out.update(xwt_W12=W12, xwt_coi=xcoi, xwt_freq=xfreq, xwt_signif=xsig)
+    W12u, _, _, xsigu = ref.xwt(y1, y2, dt, dj, -1, -1, 0.9, "morlet", False)
+    out.update(xwt_W12_unnorm=W12u, xwt_signif_unnorm=xsigu)
+    out["smooth_complex"] = m.smooth(W / sj[:, None], dt, dj, sj)
+    out["smooth_real"] = m.smooth(np.abs(W) ** 2 / sj[:, None], dt, dj, sj)
+    WCT, aWCT, wcoi, wfreq, wsig = ref.wct(y1, y2, dt, dj, -1, -1, False, 0.95, m, True)
+    out.update(wct=WCT, awct=aWCT, wct_coi=wcoi, wct_freq=wfreq, wct_sig=wsig)
+    save("callers", **out)
+
+
 if __name__ == "__main__":
+    callers()
+    sys.exit(0) if "--callers-only" in sys.argv else None
     nino3()
     small()
     mid()

@@ -34,6 +34,12 @@ SYMBOLS = [
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_fft_rows", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
+    ("cwt_filter_rows", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_boxcar_scales", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int, _P]),
+    ("cwt_wct_products", C.c_int, [_P, _P, _P, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_int64, _P, _P, _P]),
+    ("cwt_wct_coherence", C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int64, _P]),
     ("cwt_icwt_reduce", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double),
                                   C.c_double, _P]),
     ("cwt_execute_host", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
@@ -136,6 +142,31 @@ class Plan:
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
+
+    def fft_rows(self, in_dev: int, in_complex: bool, nrows: int, in_ld: int, ncols_in: int, spec_dev: int):
+        self.lib.check(self.lib.cwt_fft_rows(self.h, _P(in_dev), int(in_complex), nrows, in_ld, ncols_in,
+                                             _P(spec_dev)))
+
+    def filter_rows(self, spec_dev: int, spec_ld: int, mother: int, param: float, a, amp, W_dev: int, ldw: int,
+                    ncols: int):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        amp = np.asarray(amp, dtype=np.complex128) * np.ones(a.size)
+        ar, ai = np.ascontiguousarray(amp.real), np.ascontiguousarray(amp.imag)
+        self.lib.check(self.lib.cwt_filter_rows(self.h, _P(spec_dev), spec_ld, mother, float(param), _dptr(a),
+                                                _dptr(ar), _dptr(ai), a.size, _P(W_dev), ldw, ncols))
+
+    def boxcar_scales(self, in_dev: int, nrows: int, ld: int, ncols: int, win, out_dev: int):
+        w = np.ascontiguousarray(win, dtype=np.float64)
+        self.lib.check(self.lib.cwt_boxcar_scales(self.h, _P(in_dev), nrows, ld, ncols, _dptr(w), w.size, _P(out_dev)))
+
+    def wct_products(self, W1_dev: int, W2_dev: int, scales, ld: int, ncols: int, P_dev: int, C_dev: int,
+                     angle_dev: int):
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_wct_products(self.h, _P(W1_dev), _P(W2_dev), _dptr(s), s.size, ld, ncols,
+                                                 _P(P_dev), _P(C_dev), _P(angle_dev)))
+
+    def wct_coherence(self, S_dev: int, S12_dev: int, nrows: int, ld: int, ncols: int, out_dev: int):
+        self.lib.check(self.lib.cwt_wct_coherence(self.h, _P(S_dev), _P(S12_dev), nrows, ld, ncols, _P(out_dev)))
 
     def icwt_reduce(self, W_dev: int, ldw: int, ncols: int, scales, coeff: float, out_dev: int):
         s = np.ascontiguousarray(scales, dtype=np.float64)

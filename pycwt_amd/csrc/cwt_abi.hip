@@ -36,9 +36,9 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_PASS_A,
-                   KC_PASS_B, KC_ICWT, KC_COUNT };
+                   KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_COUNT };
 const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a", "fwd_pass_b", "small", "direct",
-                                           "narrow",    "pass_a",     "pass_b",     "icwt"};
+                                           "narrow",    "pass_a",     "pass_b",     "icwt", "elementwise"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -211,29 +211,36 @@ void profile_support(int mother, double p, double eps, double* f_lo, double* f_h
   }
 }
 
-int build_row_table(cwt_plan* p, int mother, double param, double dt, const double* scales,
-                    int nrows) {
+// Mother constant conj(c) with psi_ft(f) = c * profile(f)  (mothers.py:26-28, 118-122, 170-173)
+int mother_constant(int mother, double param, double* cre, double* cim) {
   const double pi = 3.14159265358979323846;
-  const int64_t N = p->N;
-  const double w1 = 2.0 * pi * (1.0 / (double(N) * dt));  // ftfreqs[1], wavelet.py:94
   const int m = int(std::lround(param));
-  double cre = 1.0, cim = 0.0;
+  *cre = 1.0; *cim = 0.0;
   if (mother == MOTHER_MORLET) {
-    cre = std::pow(pi, -0.25);
+    *cre = std::pow(pi, -0.25);
   } else if (mother == MOTHER_PAUL) {
     if (m < 1 || double(m) != param) return fail(CWT_EINVAL, "Paul order m must be an integer >= 1");
-    cre = std::pow(2.0, m) / std::sqrt(double(m) * std::tgamma(2.0 * m));  // (2m-1)! = Gamma(2m)
+    *cre = std::pow(2.0, m) / std::sqrt(double(m) * std::tgamma(2.0 * m));  // (2m-1)! = Gamma(2m)
   } else if (mother == MOTHER_DOG) {
     if (m < 0 || double(m) != param) return fail(CWT_EINVAL, "DOG order m must be an integer >= 0");
     const double g = 1.0 / std::sqrt(std::tgamma(m + 0.5));
     // conj(-(i^m)): m%4 = 0 -> -1, 1 -> +i, 2 -> +1, 3 -> -i
     const double tr[4] = {-1, 0, 1, 0}, ti[4] = {0, 1, 0, -1};
-    cre = tr[m & 3] * g;
-    cim = ti[m & 3] * g;
+    *cre = tr[m & 3] * g;
+    *cim = ti[m & 3] * g;
   } else {
     return fail(CWT_EINVAL, "unknown mother id");
   }
+  return CWT_OK;
+}
+
+// Row table for W[j,:] = IFFT_N( spec_j[k] * (amp_j * profile(a_j * signed_bin(k))) ), spec_j = spec + j*spec_ld.
+// a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
+int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
+                    const double* amp_im, int64_t spec_ld, int nrows) {
+  const int64_t N = p->N;
   double f_lo, f_hi;
+  if (mother < MOTHER_MORLET || mother > MOTHER_DOG) return fail(CWT_EINVAL, "unknown mother id");
   profile_support(mother, param, p->prec == 64 ? 1e-18 : 1e-9, &f_lo, &f_hi);
 
   const int logP = std::min(p->log_wg_points, p->logN);
@@ -244,13 +251,12 @@ int build_row_table(cwt_plan* p, int mother, double param, double dt, const doub
                         logP == (p->prec == 64 ? 13 : 14);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
   for (int j = 0; j < nrows; ++j) {
-    const double s = scales[j];
-    if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
+    if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
     RowDesc rd;
-    rd.a = s * w1;
-    const double norm = std::sqrt(s * w1 * double(N)) / double(N);
-    rd.amp_re = norm * cre;
-    rd.amp_im = norm * cim;
+    rd.a = a[j];
+    rd.amp_re = amp_re[j] / double(N);
+    rd.amp_im = amp_im[j] / double(N);
+    rd.spec_off = long(spec_ld) * j;
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
     klo = std::max(klo, -double(N / 2));
@@ -338,22 +344,22 @@ bool try_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<
 
 template <typename T, int LOGR, int MODE>
 void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo, long n0,
-                      cplx<T>* Z, hipStream_t st) {
+                      long in_ld, cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
   hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LOGP, MODE>), dim3(1u << (p->logN - LOGP), cnt),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), st, in, rows, mo,
-                     tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, Z);
+                     tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
 }
 
 template <typename T, int MODE>
 bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
-                   long n0, cplx<T>* Z, hipStream_t st) {
+                   long n0, long in_ld, cplx<T>* Z, hipStream_t st) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
   switch (logR) {
-    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
-    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
-    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
-    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0, Z, st); return true;
+    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
+    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
+    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
+    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
     default: return false;
   }
 }
@@ -370,45 +376,62 @@ bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>*
   return true;
 }
 
-template <typename T>
-int forward_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
+// Forward FFT of nrows rows (real, or complex for MODE = IN_CPLX), each zero padded from n0 to N:
+// out[r, k] = sum_n in[r, n] e^{-2 pi i k n / N}, computed as conj(inverse(conj(in))).
+template <typename T, int MODE>
+int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int64_t n0, void* out_dev) {
   const int logN = p->logN;
   const Mother mo{MOTHER_MORLET, 0, 0.0};
-  cplx<T>* out = static_cast<cplx<T>*>(xhat_dev);
+  cplx<T>* out = static_cast<cplx<T>*>(out_dev);
   if (logN <= 3) {
+    const int total = nrows << logN;
     return timed_launch(p, KC_FWD_SMALL, [&] {
-      hipLaunchKernelGGL((k_direct<T, IN_REAL>), dim3(1), dim3(64), 0, p->stream, x_dev,
-                         (const RowDesc*)nullptr, 1, mo, logN, long(n0), out, long(p->N), long(p->N));
+      hipLaunchKernelGGL((k_direct<T, MODE>), dim3((total + 63) / 64), dim3(64), 0, p->stream, in_dev,
+                         (const RowDesc*)nullptr, nrows, mo, logN, long(n0), long(in_ld), out, long(p->N),
+                         long(p->N));
     });
   }
   if (logN <= p->loglmax) {
-    const int threads = 1 << (logN - 4);
-    const size_t lds = (size_t(1) << logN) * sizeof(T);
+    const int logTB = nrows > 1 ? std::max(0, std::min(12, p->log_wg_points) - logN) : 0;
+    const int TB = 1 << logTB;
+    const int threads = TB << (logN - 4);
+    const size_t lds = (size_t(TB) << logN) * sizeof(T);
     return timed_launch(p, KC_FWD_SMALL, [&] {
-      hipLaunchKernelGGL((k_small<T, IN_REAL>), dim3(1), dim3(threads), lds, p->stream, x_dev,
-                         (const RowDesc*)nullptr, 1, mo, tw_table<T>(p, logN), logN, 0, long(n0), out,
-                         long(p->N), long(p->N));
+      hipLaunchKernelGGL((k_small<T, MODE>), dim3((nrows + TB - 1) / TB), dim3(threads), lds, p->stream,
+                         in_dev, (const RowDesc*)nullptr, nrows, mo, tw_table<T>(p, logN), logN, logTB,
+                         long(n0), long(in_ld), out, long(p->N), long(p->N));
     });
   }
   const int logK = two_pass_logk(p), logR = logN - logK;
   const int logP = std::min(p->log_wg_points, logN);
-  int rc = ensure_z(p, 1);
+  const int chunk = std::max(1, std::min(p->chunk_rows, nrows));
+  int rc = ensure_z(p, chunk);
   if (rc) return rc;
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   const int threads = 1 << (logP - 4);
-  rc = timed_launch(p, KC_FWD_A, [&] {
-    if (try_pass_a_ct<T, IN_REAL>(p, logR, x_dev, nullptr, 1, mo, long(n0), static_cast<cplx<T>*>(p->Z), p->stream)) return;
-    hipLaunchKernelGGL((k_pass_a<T, IN_REAL>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
-                       x_dev, (const RowDesc*)nullptr, mo, tw_table<T>(p, logR), twn_of<T>(p), logN,
-                       logK, logP - logR, long(n0), static_cast<cplx<T>*>(p->Z));
-  });
-  if (rc) return rc;
-  return timed_launch(p, KC_FWD_B, [&] {
-    if (try_pass_b_ct<T, true>(p, logK, nullptr, 1, out, p->N, p->N, static_cast<const cplx<T>*>(p->Z), p->stream)) return;
-    hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), 1), dim3(threads), lds, p->stream,
-                       static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
-                       logN, logK, logP - logK, out, long(p->N), long(p->N));
-  });
+  const size_t esz = (MODE == IN_REAL ? 1 : 2) * sizeof(T);
+  for (int first = 0; first < nrows; first += chunk) {
+    const int cnt = std::min(chunk, nrows - first);
+    const void* in = static_cast<const char*>(in_dev) + size_t(first) * size_t(in_ld) * esz;
+    cplx<T>* o = out + size_t(first) * size_t(p->N);
+    rc = timed_launch(p, KC_FWD_A, [&] {
+      if (try_pass_a_ct<T, MODE>(p, logR, in, nullptr, cnt, mo, long(n0), long(in_ld),
+                                 static_cast<cplx<T>*>(p->Z), p->stream)) return;
+      hipLaunchKernelGGL((k_pass_a<T, MODE>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
+                         in, (const RowDesc*)nullptr, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK,
+                         logP - logR, long(n0), long(in_ld), static_cast<cplx<T>*>(p->Z));
+    });
+    if (rc) return rc;
+    rc = timed_launch(p, KC_FWD_B, [&] {
+      if (try_pass_b_ct<T, true>(p, logK, nullptr, cnt, o, p->N, p->N, static_cast<const cplx<T>*>(p->Z),
+                                 p->stream)) return;
+      hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
+                         static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
+                         logN, logK, logP - logK, o, long(p->N), long(p->N));
+    });
+    if (rc) return rc;
+  }
+  return CWT_OK;
 }
 
 template <typename T>
@@ -423,7 +446,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       const int total = nrows << logN;
       return timed_launch(p, KC_DIRECT, [&] {
         hipLaunchKernelGGL((k_direct<T, IN_SPECTRUM>), dim3((total + 63) / 64), dim3(64), 0, p->stream,
-                           xhat_dev, p->rows_dev, nrows, mo, logN, 0L, W, long(ldw), long(ncols));
+                           xhat_dev, p->rows_dev, nrows, mo, logN, 0L, 0L, W, long(ldw), long(ncols));
       });
     }
     // several rows per workgroup: aim at 4096 points (256 threads)
@@ -434,7 +457,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     return timed_launch(p, KC_SMALL, [&] {
       hipLaunchKernelGGL((k_small<T, IN_SPECTRUM>), dim3((nrows + TB - 1) / TB), dim3(threads), lds,
                          p->stream, xhat_dev, p->rows_dev, nrows, mo, tw_table<T>(p, logN), logN, logTB,
-                         0L, W, long(ldw), long(ncols));
+                         0L, 0L, W, long(ldw), long(ncols));
     });
   }
   const int logP = std::min(p->log_wg_points, logN);
@@ -461,9 +484,9 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       cplx<T>* Z = static_cast<cplx<T>*>(p->Z) + size_t(buf) * size_t(chunk) * size_t(p->N);
       if (pipelined && c >= 2) HIPCHECK(hipStreamWaitEvent(sa, p->ev_b[buf], 0));   // buffer is free again
       rc = timed_launch(p, KC_PASS_A, [&] {
-        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, Z, sa)) return;
+        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, 0L, Z, sa)) return;
         hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sa,
-                           xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, Z);
+                           xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, 0L, Z);
       }, sa);
       if (rc) return rc;
       if (pipelined) {
@@ -514,6 +537,8 @@ int set_func_attrs() {
   const int big = 128 * 1024;
   const void* fns[] = {reinterpret_cast<const void*>(&k_small<T, IN_REAL>),
                        reinterpret_cast<const void*>(&k_small<T, IN_SPECTRUM>),
+                       reinterpret_cast<const void*>(&k_small<T, IN_CPLX>),
+                       reinterpret_cast<const void*>(&k_pass_a<T, IN_CPLX>),
                        reinterpret_cast<const void*>(&k_narrow<T>),
                        reinterpret_cast<const void*>(&k_pass_a<T, IN_REAL>),
                        reinterpret_cast<const void*>(&k_pass_a<T, IN_SPECTRUM>),
@@ -668,9 +693,21 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  return p->prec == 64 ? forward_impl<double>(p, x_dev, n0, xhat_dev)
-                       : forward_impl<float>(p, x_dev, n0, xhat_dev);
+  return p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
+                       : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
 }
+
+namespace {
+int run_filter_rows(cwt_plan* p, const void* spec_dev, int mother, double param, int nrows, void* W_dev,
+                    int64_t ldw, int64_t ncols) {
+  HIPCHECK(hipStreamSynchronize(p->stream));  // the pinned staging buffer may still be in flight
+  std::memcpy(p->rows_pinned, p->table.data(), p->table.size() * sizeof(RowDesc));
+  HIPCHECK(hipMemcpyAsync(p->rows_dev, p->rows_pinned, p->table.size() * sizeof(RowDesc),
+                          hipMemcpyHostToDevice, p->stream));
+  (void)nrows;
+  return CWT_OK;
+}
+}  // namespace
 
 int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double param, double dt,
                        const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
@@ -684,12 +721,21 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
                     std::equal(scales, scales + nrows, p->last_scales.begin());
   if (!same) {
     p->table_valid = false;
-    int rc = build_row_table(p, mother, param, dt, scales, nrows);
+    double cre, cim;
+    int rc = mother_constant(mother, param, &cre, &cim);
     if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(p->stream));  // the pinned staging buffer may still be in flight
-    std::memcpy(p->rows_pinned, p->table.data(), p->table.size() * sizeof(RowDesc));
-    HIPCHECK(hipMemcpyAsync(p->rows_dev, p->rows_pinned, p->table.size() * sizeof(RowDesc),
-                            hipMemcpyHostToDevice, p->stream));
+    const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(p->N) * dt));  // ftfreqs[1], wavelet.py:94
+    std::vector<double> a(nrows), ar(nrows), ai(nrows);
+    for (int j = 0; j < nrows; ++j) {
+      if (!(scales[j] > 0) || !std::isfinite(scales[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
+      a[j] = scales[j] * w1;
+      const double norm = std::sqrt(scales[j] * w1 * double(p->N));                 // wavelet.py:102
+      ar[j] = norm * cre;
+      ai[j] = norm * cim;
+    }
+    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows);
+    if (!rc) rc = run_filter_rows(p, xhat_dev, mother, param, nrows, W_dev, ldw, ncols);
+    if (rc) return rc;
     p->last_mother = mother; p->last_param = param; p->last_dt = dt;
     p->last_scales.assign(scales, scales + nrows);
     p->table_valid = true;
@@ -699,6 +745,119 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
+}
+
+int cwt_fft_rows(cwt_plan* p, const void* in_dev, int in_complex, int nrows, int64_t in_ld, int64_t ncols_in,
+                 void* spec_dev) {
+  if (!p || !in_dev || !spec_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1) return fail(CWT_EINVAL, "nrows must be >= 1");
+  if (ncols_in < 1 || ncols_in > p->N || in_ld < ncols_in) return fail(CWT_EINVAL, "need 1 <= ncols_in <= nfft and in_ld >= ncols_in");
+  HIPCHECK(hipSetDevice(p->device));
+  if (p->prec == 64)
+    return in_complex ? fft_rows_impl<double, IN_CPLX>(p, in_dev, in_ld, nrows, ncols_in, spec_dev)
+                      : fft_rows_impl<double, IN_REAL>(p, in_dev, in_ld, nrows, ncols_in, spec_dev);
+  return in_complex ? fft_rows_impl<float, IN_CPLX>(p, in_dev, in_ld, nrows, ncols_in, spec_dev)
+                    : fft_rows_impl<float, IN_REAL>(p, in_dev, in_ld, nrows, ncols_in, spec_dev);
+}
+
+int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int mother, double param,
+                    const double* a, const double* amp_re, const double* amp_im, int nrows, void* W_dev,
+                    int64_t ldw, int64_t ncols) {
+  if (!p || !spec_dev || !a || !amp_re || !amp_im || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
+  if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
+  if (spec_ld != 0 && spec_ld < p->N) return fail(CWT_EINVAL, "spec_ld must be 0 (shared) or >= nfft");
+  HIPCHECK(hipSetDevice(p->device));
+  p->table_valid = false;
+  double cre, cim;
+  int rc = mother_constant(mother, param, &cre, &cim);   // validates mother / order only
+  if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
+  if (!rc) rc = run_filter_rows(p, spec_dev, mother, param, nrows, W_dev, ldw, ncols);
+  if (rc) return rc;
+  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  Mother mo;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param;
+  return p->prec == 64 ? rows_impl<double>(p, spec_dev, mo, nrows, W_dev, ldw, ncols)
+                       : rows_impl<float>(p, spec_dev, mo, nrows, W_dev, ldw, ncols);
+}
+
+extern "C++" {
+namespace {
+template <typename T>
+int upload_reals(cwt_plan* p, const double* v, int n) {          // -> p->weights_dev as T[n]
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  for (int j = 0; j < n; ++j) {
+    if (sizeof(T) == 8) static_cast<double*>(p->weights_pinned)[j] = v[j];
+    else static_cast<float*>(p->weights_pinned)[j] = float(v[j]);
+  }
+  HIPCHECK(hipMemcpyAsync(p->weights_dev, p->weights_pinned, size_t(n) * sizeof(T), hipMemcpyHostToDevice, p->stream));
+  return CWT_OK;
+}
+
+template <typename T>
+int wct_products_impl(cwt_plan* p, const void* W1, const void* W2, const double* scales, int nrows, int64_t ld,
+                      int64_t ncols, void* P, void* C, void* A) {
+  std::vector<double> inv(nrows);
+  for (int j = 0; j < nrows; ++j) inv[j] = 1.0 / scales[j];
+  int rc = upload_reals<T>(p, inv.data(), nrows);
+  if (rc) return rc;
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    hipLaunchKernelGGL((k_wct_products<T>), dim3(unsigned((ncols + 255) / 256), nrows), dim3(256), 0, p->stream,
+                       static_cast<const cplx<T>*>(W1), static_cast<const cplx<T>*>(W2),
+                       static_cast<const T*>(p->weights_dev), long(ld), long(ncols), static_cast<cplx<T>*>(P),
+                       static_cast<cplx<T>*>(C), static_cast<T*>(A));
+  });
+}
+
+template <typename T>
+int boxcar_impl(cwt_plan* p, const void* in, int nrows, int64_t ld, int64_t ncols, const double* win, int nwin,
+                void* out) {
+  int rc = upload_reals<T>(p, win, nwin);
+  if (rc) return rc;
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    hipLaunchKernelGGL((k_boxcar_scales<T>), dim3(unsigned((ncols + 255) / 256), nrows), dim3(256), 0, p->stream,
+                       static_cast<const cplx<T>*>(in), nrows, long(ld), long(ncols),
+                       static_cast<const T*>(p->weights_dev), nwin, static_cast<cplx<T>*>(out));
+  });
+}
+
+template <typename T>
+int coherence_impl(cwt_plan* p, const void* S, const void* S12, int nrows, int64_t ld, int64_t ncols, void* out) {
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    hipLaunchKernelGGL((k_wct_coherence<T>), dim3(unsigned((ncols + 255) / 256), nrows), dim3(256), 0, p->stream,
+                       static_cast<const cplx<T>*>(S), static_cast<const cplx<T>*>(S12), long(ld), long(ncols),
+                       static_cast<T*>(out));
+  });
+}
+}  // namespace
+}  // extern "C++"
+
+int cwt_wct_products(cwt_plan* p, const void* W1_dev, const void* W2_dev, const double* scales, int nrows,
+                     int64_t ld, int64_t ncols, void* P_dev, void* C_dev, void* angle_dev) {
+  if (!p || !W1_dev || !W2_dev || !scales || !P_dev || !C_dev || !angle_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? wct_products_impl<double>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev)
+                       : wct_products_impl<float>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev);
+}
+
+int cwt_boxcar_scales(cwt_plan* p, const void* in_dev, int nrows, int64_t ld, int64_t ncols, const double* win,
+                      int nwin, void* out_dev) {
+  if (!p || !in_dev || !win || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || ncols < 1 || ld < ncols || nwin < 1 || nwin > p->max_rows) return fail(CWT_EINVAL, "bad shape");
+  if (in_dev == out_dev) return fail(CWT_EINVAL, "boxcar cannot run in place");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? boxcar_impl<double>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev)
+                       : boxcar_impl<float>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev);
+}
+
+int cwt_wct_coherence(cwt_plan* p, const void* S_dev, const void* S12_dev, int nrows, int64_t ld, int64_t ncols,
+                      void* out_dev) {
+  if (!p || !S_dev || !S12_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? coherence_impl<double>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev)
+                       : coherence_impl<float>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev);
 }
 
 int cwt_icwt_reduce(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,

@@ -23,7 +23,7 @@
 namespace cwt {
 
 enum : int { MOTHER_MORLET = 0, MOTHER_PAUL = 1, MOTHER_DOG = 2 };
-enum : int { IN_SPECTRUM = 0, IN_REAL = 1 };
+enum : int { IN_SPECTRUM = 0, IN_REAL = 1, IN_CPLX = 2 };   // IN_CPLX: complex rows, conjugated on load
 
 // One row (scale) of the transform, prepared on the host in double precision.
 struct RowDesc {
@@ -35,6 +35,7 @@ struct RowDesc {
   int out_row;     // destination row of W
   int logK;        // k_narrow: log2 of this row's FFT length
   int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
+  long spec_off;   // element offset of this row's spectrum (0: all rows share one spectrum)
 };
 
 struct Mother {
@@ -111,7 +112,7 @@ __device__ __forceinline__ cplx<T> filtered_bin(const cplx<T>* __restrict__ xhat
   const unsigned d = unsigned(ks - rd.k_lo);
   if (d >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
   const T g = profile<T>(mo, T(rd.a) * T(ks));
-  const cplx<T> x = xhat[ks & nmask];
+  const cplx<T> x = (xhat + rd.spec_off)[ks & nmask];
   const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
   return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
 }
@@ -125,8 +126,8 @@ __device__ __forceinline__ int signed_bin(int k, int N) { return k < (N >> 1) ? 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(CWT_MAX_THREADS)
 k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows, Mother mo,
-        const cplx<T>* __restrict__ tw, int logN, int logTB, long n0, cplx<T>* __restrict__ out,
-        long ldw, long ncols) {
+        const cplx<T>* __restrict__ tw, int logN, int logTB, long n0, long in_ld,
+        cplx<T>* __restrict__ out, long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   const int N = 1 << logN, logNT = logN - 4, NT = 1 << logNT;
@@ -138,17 +139,25 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   const bool live = row < nrows;
   T re[16], im[16];
   if constexpr (MODE == IN_REAL) {
-    const T* x = static_cast<const T*>(in);
+    const T* x = static_cast<const T*>(in) + long(row) * in_ld;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = g.j + (e << logNT);
       re[e] = (live && k < n0) ? x[k] : T(0);
       im[e] = T(0);
     }
+  } else if constexpr (MODE == IN_CPLX) {
+    const cplx<T>* x = static_cast<const cplx<T>*>(in) + long(row) * in_ld;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = g.j + (e << logNT);
+      const cplx<T> v = (live && k < n0) ? x[k] : mk<T>(T(0), T(0));
+      re[e] = v.x; im[e] = -v.y;
+    }
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
     RowDesc rd;
-    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; }
+    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = g.j + (e << logNT);
@@ -158,18 +167,18 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   }
   wg_ifft<T, false>(re, im, lds, g, tw);
   if (!live) return;
-  const long orow = (MODE == IN_REAL) ? 0 : long(rows[row].out_row);
+  const long orow = (MODE != IN_SPECTRUM) ? long(row) : long(rows[row].out_row);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const long m = g.j + (e << logNT);
-    if (m < ncols) out[orow * ldw + m] = mk<T>(re[e], MODE == IN_REAL ? -im[e] : im[e]);
+    if (m < ncols) out[orow * ldw + m] = mk<T>(re[e], MODE != IN_SPECTRUM ? -im[e] : im[e]);
   }
 }
 
 // k_direct: N <= 8.  One thread per output element.
 template <typename T, int MODE>
 __global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows,
-                         Mother mo, int logN, long n0, cplx<T>* __restrict__ out, long ldw,
+                         Mother mo, int logN, long n0, long in_ld, cplx<T>* __restrict__ out, long ldw,
                          long ncols) {
   const int N = 1 << logN;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,8 +188,11 @@ __global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict_
   for (int k = 0; k < N; ++k) {
     double yr, yi;
     if constexpr (MODE == IN_REAL) {
-      yr = (k < n0) ? double(static_cast<const T*>(in)[k]) : 0.0;
+      yr = (k < n0) ? double((static_cast<const T*>(in) + long(row) * in_ld)[k]) : 0.0;
       yi = 0;
+    } else if constexpr (MODE == IN_CPLX) {
+      const cplx<T> v = (k < n0) ? (static_cast<const cplx<T>*>(in) + long(row) * in_ld)[k] : mk<T>(T(0), T(0));
+      yr = v.x; yi = -v.y;
     } else {
       const cplx<T> v = filtered_bin<T>(static_cast<const cplx<T>*>(in), rows[row], mo,
                                         signed_bin(k, N), N - 1);
@@ -191,8 +203,8 @@ __global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict_
     sr += yr * c - yi * s;
     si += yr * s + yi * c;
   }
-  const long orow = (MODE == IN_REAL) ? 0 : long(rows[row].out_row);
-  out[orow * ldw + m] = mk<T>(T(sr), T(MODE == IN_REAL ? -si : si));
+  const long orow = (MODE != IN_SPECTRUM) ? long(row) : long(rows[row].out_row);
+  out[orow * ldw + m] = mk<T>(T(sr), T(MODE != IN_SPECTRUM ? -si : si));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,7 +275,7 @@ k_narrow(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mot
 template <typename T, int MODE>
 __global__ void __launch_bounds__(CWT_MAX_THREADS)
 k_pass_a(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,
-         const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, int logK, int logTQ, long n0,
+         const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, int logK, int logTQ, long n0, long in_ld,
          cplx<T>* __restrict__ Z) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
@@ -275,12 +287,20 @@ k_pass_a(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother m
   const int q = (blockIdx.x << logTQ) + g.t;
   T re[16], im[16];
   if constexpr (MODE == IN_REAL) {
-    const T* x = static_cast<const T*>(in);
+    const T* x = static_cast<const T*>(in) + long(blockIdx.y) * in_ld;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const long k = q + (long(g.j + (e << logNT)) << logK);
       re[e] = k < n0 ? x[k] : T(0);
       im[e] = T(0);
+    }
+  } else if constexpr (MODE == IN_CPLX) {
+    const cplx<T>* x = static_cast<const cplx<T>*>(in) + long(blockIdx.y) * in_ld;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long k = q + (long(g.j + (e << logNT)) << logK);
+      const cplx<T> v = k < n0 ? x[k] : mk<T>(T(0), T(0));
+      re[e] = v.x; im[e] = -v.y;
     }
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
@@ -345,7 +365,7 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 #pragma unroll
   for (int c = 0; c < 16; ++c) im[c] = lds[lds_swizzle<T>(threadIdx.x + c * blockDim.x)];
 
-  const long orow = rows ? long(rows[blockIdx.y].out_row) : 0;
+  const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
   cplx<T>* wrow = W + orow * ldw;
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -451,7 +471,8 @@ k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 template <typename T, int LOGR, int LOGP, int MODE>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,
-            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, long n0, cplx<T>* __restrict__ Z) {
+            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, long n0, long in_ld,
+            cplx<T>* __restrict__ Z) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int LOGTQ = LOGP - LOGR, LOGNT = LOGR - 4, NT = 1 << LOGNT;
@@ -464,12 +485,20 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
   const unsigned k0 = q + (unsigned(f.j) << logK);        // bin of slot 0; slot e adds (e*NT) << logK
   T re[16], im[16];
   if constexpr (MODE == IN_REAL) {
-    const T* x = static_cast<const T*>(in);
+    const T* x = static_cast<const T*>(in) + long(blockIdx.y) * in_ld;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const unsigned step_e = unsigned(e * NT) << logK;
       re[e] = (long(k0) + step_e < n0) ? (x + step_e)[k0] : T(0);
       im[e] = T(0);
+    }
+  } else if constexpr (MODE == IN_CPLX) {
+    const cplx<T>* x = static_cast<const cplx<T>*>(in) + long(blockIdx.y) * in_ld;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned step_e = unsigned(e * NT) << logK;
+      const cplx<T> v = (long(k0) + step_e < n0) ? (x + step_e)[k0] : mk<T>(T(0), T(0));
+      re[e] = v.x; im[e] = -v.y;
     }
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
@@ -534,7 +563,7 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 #pragma unroll
   for (int c = 0; c < 16; ++c) im[c] = lds[rbase + c * TS];
 
-  const long orow = rows ? long(rows[blockIdx.y].out_row) : 0;
+  const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
   cplx<T>* wrow = W + orow * ldw;
   const unsigned m0 = threadIdx.x >> LOGTB, tt = threadIdx.x & ((1 << LOGTB) - 1);
   const unsigned off = (m0 << logR) + r0 + tt;
@@ -543,6 +572,59 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const unsigned step_c = unsigned(c * (BD >> LOGTB)) << logR;
     if (long(off) + step_c < ncols) store_w<T>(wrow + step_c + off, re[c], CONJ ? -im[c] : im[c]);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise helpers of the coherence path (pycwt/wavelet.py:499-514, mothers.py:97-102).
+// All matrices are rows x ld, row-major, n < ncols valid.
+
+// P[j,n] = (|W1|^2 + i |W2|^2) / s_j   (both auto-spectra ride through ONE complex smoothing pass:
+//                                       the smoothing kernel is real, so Re/Im stay separate)
+// C[j,n] = W1 conj(W2) / s_j ;  A[j,n] = angle(W1 conj(W2))
+template <typename T>
+__global__ void k_wct_products(const cplx<T>* __restrict__ W1, const cplx<T>* __restrict__ W2,
+                               const T* __restrict__ inv_s, long ld, long ncols, cplx<T>* __restrict__ P,
+                               cplx<T>* __restrict__ C, T* __restrict__ A) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  const long i = long(blockIdx.y) * ld + n;
+  const cplx<T> a = W1[i], b = W2[i];
+  const T is = inv_s[blockIdx.y];
+  P[i] = mk<T>((a.x * a.x + a.y * a.y) * is, (b.x * b.x + b.y * b.y) * is);
+  const T cr = a.x * b.x + a.y * b.y, ci = a.y * b.x - a.x * b.y;
+  C[i] = mk<T>(cr * is, ci * is);
+  A[i] = atan2(ci, cr);
+}
+
+// Boxcar along the scale axis = scipy.signal.convolve2d(T, win[:, None], 'same') (zero boundary):
+// out[j] = sum_i win[i] T[j + (L-1)/2 - i]
+template <typename T>
+__global__ void k_boxcar_scales(const cplx<T>* __restrict__ in, int nrows, long ld, long ncols,
+                                const T* __restrict__ win, int L, cplx<T>* __restrict__ out) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  const int j = blockIdx.y, c = (L - 1) / 2;
+  T sr = 0, si = 0;
+  for (int i = 0; i < L; ++i) {
+    const int jj = j + c - i;
+    if (jj >= 0 && jj < nrows) {
+      const cplx<T> v = in[long(jj) * ld + n];
+      sr += win[i] * v.x;
+      si += win[i] * v.y;
+    }
+  }
+  out[long(j) * ld + n] = mk<T>(sr, si);
+}
+
+// WCT = |S12|^2 / (S1 S2) with S = S1 + i S2
+template <typename T>
+__global__ void k_wct_coherence(const cplx<T>* __restrict__ S, const cplx<T>* __restrict__ S12, long ld,
+                                long ncols, T* __restrict__ out) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  const long i = long(blockIdx.y) * ld + n;
+  const cplx<T> s = S[i], c = S12[i];
+  out[i] = (c.x * c.x + c.y * c.y) / (s.x * s.y);
 }
 
 // ---------------------------------------------------------------------------------------------

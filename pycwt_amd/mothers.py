@@ -68,6 +68,26 @@ class Morlet(_Mother):
     def device_id(self):
         return _hip.MORLET, float(self.f0)
 
+    def smooth(self, W, dt, dj, scales, *, precision=None, device=0):
+        """Coherence smoothing operator (mothers.py:61-104): Gaussian of width s/dt along time (FFT
+        filter, on the GPU) and a 2*deltaj0/dj boxcar along scales.  Real input gives real output."""
+        from . import wavelet as _w
+        W = np.asarray(W)
+        rows, n = W.shape
+        precision = _w._default_precision() if precision is None else int(precision)
+        plan = _w._plan(_w._next_pow2(n), precision, device, rows)
+        es = np.dtype(plan.real).itemsize
+        sc = _w._Scratch(device)
+        try:
+            T, tmp, out = (sc.new(rows * n * 2 * es) for _ in range(3))
+            spec = sc.new(rows * plan.nfft * 2 * es)
+            T.upload(plan, np.ascontiguousarray(W, dtype=plan.cplx))
+            _w._smooth_on_device(plan, self, T, rows, n, dt, dj, np.asarray(scales, dtype=float), spec, tmp, out)
+            res = out.download(plan, (rows, n), plan.cplx).astype(np.complex128)
+        finally:
+            sc.free()
+        return res.real if np.isreal(W).all() else res
+
 
 class Paul(_Mother):
     """Paul wavelet of integer order ``m`` (reference: mothers.py:107-155)."""

@@ -14,7 +14,10 @@ import os
 
 import numpy as np
 
+from scipy.stats import chi2
+
 from . import _hip
+from .helpers import ar1, ar1_spectrum, find, get_cache_dir, rednoise
 from .mothers import DOG, MexicanHat, Morlet, Paul
 
 _MOTHERS = {"morlet": Morlet, "paul": Paul, "dog": DOG, "mexicanhat": MexicanHat}
@@ -146,3 +149,223 @@ def icwt(W, sj, dt, dj=1 / 12, wavelet="morlet", *, precision=None, device=0):
     if col_scale is not None:
         total = total / np.sqrt(col_scale)
     return dj * np.sqrt(dt) / (mother.cdelta * mother.psi(0)) * total
+
+
+# =============================================================================================
+# Callers of the hot path.  Same signatures as the reference.
+# =============================================================================================
+def significance(signal, dt, scales, sigma_test=0, alpha=None, significance_level=0.95, dof=-1,
+                 wavelet="morlet"):
+    """Chi-square significance levels against an AR(1) background (wavelet.py:174-313, TC98 sec. 4-5).
+
+    sigma_test 0: point-wise test (eq. 18); 1: time-averaged (eq. 23, `dof` = number of averaged
+    points per scale); 2: scale-averaged over [s1, s2] = `dof` (eq. 25-28).  Host arithmetic, O(J).
+    Returns (signif, fft_theor).
+    """
+    mother = _check_parameter_wavelet(wavelet)
+    scales = np.asarray(scales, dtype=float)
+    try:
+        n0 = len(signal)
+    except TypeError:
+        n0 = 1
+    variance = signal if n0 == 1 else np.asarray(signal).std() ** 2
+    if alpha is None:
+        alpha, _, _ = ar1(signal)
+    dj = np.log2(scales[1] / scales[0])
+    freq = dt / (scales * mother.flambda())                    # normalised frequency of each scale
+    # red-noise spectrum, TC98 eq. 16
+    fft_theor = variance * (1 - alpha ** 2) / (1 + alpha ** 2 - 2 * alpha * np.cos(2 * np.pi * freq / n0))
+    dofmin = mother.dofmin
+    if sigma_test == 0:
+        signif = fft_theor * chi2.ppf(significance_level, dofmin) / dofmin
+    elif sigma_test == 1:
+        navg = np.atleast_1d(np.asarray(dofmin if np.isscalar(dof) and dof == -1 else dof, dtype=float))
+        navg = np.broadcast_to(navg, scales.shape).copy() if navg.size == 1 else navg.copy()
+        navg[navg < 1] = 1
+        edof = dofmin * np.sqrt(1 + (navg * dt / mother.gamma / scales) ** 2)      # eq. 23
+        edof[edof < dofmin] = dofmin
+        signif = fft_theor * chi2.ppf(significance_level, edof) / edof
+    elif sigma_test == 2:
+        if np.isscalar(dof) or len(dof) != 2:
+            raise Exception("DOF must be set to [s1, s2], the range of scale-averages")
+        if mother.cdelta == -1:
+            raise ValueError("Cdelta and dj0 not defined for {} with f0={}".format(
+                mother.name, getattr(mother, "f0", getattr(mother, "m", None))))
+        s1, s2 = dof
+        sel = find((scales >= s1) & (scales <= s2))
+        if sel.size == 0:
+            raise ValueError("No valid scales between {} and {}.".format(s1, s2))
+        savg = 1 / np.sum(1. / scales[sel])                                          # eq. 25
+        smid = np.exp((np.log(s1) + np.log(s2)) / 2.)
+        edof = (dofmin * sel.size * savg / smid) * np.sqrt(1 + (sel.size * dj / mother.deltaj0) ** 2)  # eq. 28
+        fft_theor = savg * np.sum(fft_theor[sel] / scales[sel])                      # eq. 27
+        signif = (dj * dt / mother.cdelta / savg) * fft_theor * chi2.ppf(significance_level, edof) / edof
+    else:
+        raise ValueError("sigma_test must be either 0, 1, or 2.")
+    return signif, fft_theor
+
+
+def _normalised(y, normalize):
+    y = np.asarray(y)
+    return ((y - y.mean()) / y.std()) if normalize else y
+
+
+def xwt(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wavelet="morlet", normalize=True,
+        *, precision=None, device=0):
+    """Cross wavelet transform W1 conj(W2) with its AR(1) chi-square level (wavelet.py:316-419).
+    Returns (W12, coi, freq, signif)."""
+    mother = _check_parameter_wavelet(wavelet)
+    y1, y2 = np.asarray(y1), np.asarray(y2)
+    std1, std2 = (1., 1.) if normalize else (y1.std(), y2.std())
+    kw = dict(dj=dj, s0=s0, J=J, wavelet=mother, precision=precision, device=device)
+    W1, sj, freq, coi, _, _ = cwt(_normalised(y1, normalize), dt, **kw)
+    W2, sj, freq, coi, _, _ = cwt(_normalised(y2, normalize), dt, **kw)
+    W12 = W1 * W2.conj()
+    a1, a2 = ar1(y1)[0], ar1(y2)[0]
+    pk = np.sqrt(ar1_spectrum(freq * dt, a1) * ar1_spectrum(freq * dt, a2))
+    dof = mother.dofmin
+    signif = std1 * std2 * pk * chi2.ppf(significance_level, dof) / dof
+    return W12, coi, freq, signif
+
+
+class _Scratch:
+    """Device buffers of one wct evaluation, freed together."""
+
+    def __init__(self, device):
+        self.device, self.bufs = device, []
+
+    def new(self, nbytes):
+        b = _hip.DeviceBuffer(nbytes, self.device)
+        self.bufs.append(b)
+        return b
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+        self.bufs = []
+
+
+def _smooth_on_device(plan, mother, T, rows, n, dt, dj, sj, spec, tmp, out):
+    """mothers.py:61-104 on device: per-row FFT -> Gaussian of width s/dt -> inverse FFT -> boxcar over
+    scales.  T, tmp, out: rows x n complex; spec: rows x nfft complex."""
+    from .helpers import rect
+    plan.fft_rows(T.ptr, True, rows, n, n, spec.ptr)
+    a = (np.asarray(sj) / dt) * (2 * np.pi / plan.nfft)             # exp(-0.5*(s/dt)^2*k^2), k = 2*pi*fftfreq
+    plan.filter_rows(spec.ptr, plan.nfft, _hip.DOG, 0.0, a, 1.0, tmp.ptr, n, n)
+    win = rect(int(np.round(mother.deltaj0 / dj * 2)), normalize=True)
+    plan.boxcar_scales(tmp.ptr, rows, n, n, win, out.ptr)
+
+
+def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_angle=True):
+    """|S12|^2/(S1 S2) and arg(W1 conj W2) for two equally long series, all on the GPU; only the two
+    real result matrices cross PCIe."""
+    n0 = len(x1)
+    N = _next_pow2(n0)
+    rows = len(sj)
+    kind, param = _device_id(mother)
+    plan = _plan(N, precision, device, rows)
+    es = np.dtype(plan.real).itemsize
+    sc = _Scratch(device)
+    try:
+        xd, xh = sc.new(n0 * es), sc.new(N * 2 * es)
+        W1, W2 = sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * 2 * es)
+        for x, W in ((x1, W1), (x2, W2)):
+            xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
+            plan.forward_fft(xd.ptr, n0, xh.ptr)
+            plan.transform_rows(xh.ptr, kind, param, dt, sj, W.ptr, n0, n0)
+        P, Cx, ang = sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * es)
+        plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
+        spec = sc.new(rows * N * 2 * es)
+        tmp, S, S12 = W1, W2, sc.new(rows * n0 * 2 * es)            # W1/W2 are dead after the products
+        _smooth_on_device(plan, mother, P, rows, n0, dt, dj, sj, spec, tmp, S)
+        _smooth_on_device(plan, mother, Cx, rows, n0, dt, dj, sj, spec, tmp, S12)
+        plan.wct_coherence(S.ptr, S12.ptr, rows, n0, n0, P.ptr)     # result (reals) re-uses P's storage
+        wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64)
+        awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64) if want_angle else None
+        return wct_, awct
+    finally:
+        sc.free()
+
+
+def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, wavelet="morlet",
+        normalize=True, *, precision=None, device=0, **kwargs):
+    """Wavelet coherence (wavelet.py:422-528).  Returns (WCT, aWCT, coi, freq, sig).
+
+    Both transforms, the three smoothings (two of them packed into one complex pass) and the
+    coherence ratio run on the GPU without W ever leaving the device.  `sig=True` runs the Monte-Carlo
+    significance of `wct_significance` (300 surrogate pairs by default, cached on disk like the
+    reference); pass `sig=False` to skip it.
+    """
+    mother = _check_parameter_wavelet(wavelet)
+    if not hasattr(mother, "deltaj0") or mother.deltaj0 == -1 or not isinstance(mother, Morlet):
+        raise AttributeError("wct needs a mother with a smoothing operator (Morlet), as in the reference")
+    precision = _default_precision() if precision is None else int(precision)
+    y1, y2 = np.asarray(y1), np.asarray(y2)
+    if s0 == -1:
+        s0 = 2 * dt / mother.flambda()
+    if J == -1:
+        J = int(np.round(np.log2(y1.size * dt / s0) / dj))
+    sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+    freq = 1 / (mother.flambda() * sj)
+    n0 = y1.size
+    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    WCT, aWCT = _coherence_on_device(_normalised(y1, normalize), _normalised(y2, normalize), dt, dj, sj,
+                                     mother, precision, device)
+    if sig:
+        a1, a2 = ar1(y1)[0], ar1(y2)[0]
+        sig = wct_significance(a1, a2, dt=dt, dj=dj, s0=s0, J=J, significance_level=significance_level,
+                               wavelet=mother, precision=precision, device=device, **kwargs)
+    else:
+        sig = np.asarray([0])
+    return WCT, aWCT, coi, freq, sig
+
+
+def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
+                     progress=True, cache=True, *, precision=None, device=0):
+    """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of AR(1)
+    surrogates, coherence of each pair on the GPU, per-scale histogram of the values outside the cone
+    of influence, `significance_level` percentile.  Scales that never leave the COI get NaN.  Results
+    are cached in the reference's file format under `get_cache_dir()`.  Statistical parity only (the
+    reference draws from the unseeded global RNG, helpers.py:170)."""
+    mother = _check_parameter_wavelet(wavelet)
+    precision = _default_precision() if precision is None else int(precision)
+    if cache:
+        with np.errstate(invalid="ignore", divide="ignore"):      # |4*al| > 1 gives nan, as in the reference
+            aa = np.round(np.arctanh(np.array([al1, al2]) * 4))
+        aa = np.abs(aa) + 0.5 * (aa < 0)
+        path = os.path.join(get_cache_dir(), "wct_sig_{:0.5f}_{:0.5f}_{:0.5f}_{:0.5f}_{:d}_{}.gz".format(
+            aa[0], aa[1], dj, s0 / dt, int(J), mother.name))
+        if os.path.exists(path):
+            return np.loadtxt(path, unpack=True)
+    N = int(np.ceil(s0 * (2 ** (J * dj)) / dt * 6))
+    sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+    period = mother.flambda() * sj
+    coi = mother.flambda() * mother.coi() * dt * (N / 2 - np.abs(np.arange(0, N) - (N - 1) / 2))
+    outside = period[:, None] <= coi[None, :]
+    rows_with_data = outside.any(axis=1)
+    sig95 = np.zeros(J + 1)
+    sig95[rows_with_data] = np.nan
+    maxscale = find(rows_with_data)[-1]
+    nbins = 1000
+    hist = np.zeros((J + 1, nbins))
+    it = range(mc_count)
+    if progress:
+        try:
+            from tqdm import tqdm
+            it = tqdm(it)
+        except ImportError:
+            pass
+    for _ in it:
+        r2, _ = _coherence_on_device(rednoise(N, al1, 1), rednoise(N, al2, 1), dt, dj, sj, mother, precision,
+                                     device, want_angle=False)
+        for s in range(maxscale):
+            v = np.floor(r2[s, outside[s]] * nbins).astype(int)
+            hist[s] += np.bincount(v[(v >= 0) & (v < nbins)], minlength=nbins)
+    centres = (np.arange(nbins) + 0.5) / nbins
+    for s in range(maxscale):
+        sel = hist[s] > 0
+        cum = hist[s, sel].cumsum()
+        sig95[s] = np.interp(significance_level, (cum - 0.5) / cum[-1], centres[sel])
+    if cache:
+        np.savetxt(path, sig95)
+    return sig95

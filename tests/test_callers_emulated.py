@@ -1,0 +1,102 @@
+"""Callers of the hot path: significance, xwt, Morlet.smooth, wct and the host
+helpers, against fixtures produced by the unmodified reference (oracle/gen_golden.py: callers()).
+Kernels run on the CPU emulation here; tests/test_gpu_parity.py repeats the device part on the GPU."""
+import numpy as np
+import pytest
+
+import pycwt_amd
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def g():
+    return load_golden("callers")
+
+
+def test_host_helpers(g):
+    np.testing.assert_allclose(pycwt_amd.ar1(g["y1"]), g["ar1_y1"], rtol=1e-12)
+    np.testing.assert_allclose(pycwt_amd.ar1(g["y2"]), g["ar1_y2"], rtol=1e-12)
+    m = pycwt_amd.Morlet(6)
+    freqs = 1 / (m.flambda() * g["sj"])
+    np.testing.assert_allclose(pycwt_amd.ar1_spectrum(freqs * float(g["dt"]), 0.55), g["ar1_spec"], rtol=1e-13)
+    np.testing.assert_allclose(pycwt_amd.helpers.rect(7, normalize=True), g["rect7"])
+    np.testing.assert_allclose(pycwt_amd.helpers.rect(1, True), g["rect1"])
+    assert list(pycwt_amd.find(np.array([[0, 1], [1, 0]]))) == [1, 2]
+    with pytest.raises(Warning):
+        pycwt_amd.ar1(np.arange(5.0))              # strong trend: no real root, raised like the reference
+    r = pycwt_amd.rednoise(4000, 0.7)
+    assert r.shape == (4000,) and abs(pycwt_amd.ar1(r)[0] - 0.7) < 0.08
+    assert pycwt_amd.rednoise(10, 0).shape == (10,)  # the reference crashes here (np.randn)
+    assert pycwt_amd.get_cache_dir().endswith("/.cache/pycwt/")
+
+
+def test_significance_three_tests(g):
+    y1, dt, sj = g["y1"], float(g["dt"]), g["sj"]
+    m = pycwt_amd.Morlet(6)
+    s0, f0 = pycwt_amd.significance(y1, dt, sj, 0, None, 0.95, -1, m)
+    np.testing.assert_allclose(s0, g["sig0"], rtol=1e-12)
+    np.testing.assert_allclose(f0, g["fft0"], rtol=1e-12)
+    s1, f1 = pycwt_amd.significance(y1.std() ** 2, dt, sj, 1, 0.6, 0.95, y1.size - sj, m)
+    np.testing.assert_allclose(s1, g["sig1"], rtol=1e-12)
+    s2, f2 = pycwt_amd.significance(y1.std() ** 2, dt, sj, 2, 0.6, 0.95, [2, 8], "morlet")
+    np.testing.assert_allclose(np.atleast_1d(s2), g["sig2"], rtol=1e-12)
+    np.testing.assert_allclose(np.atleast_1d(f2), g["fft2"], rtol=1e-12)
+    with pytest.raises(ValueError):
+        pycwt_amd.significance(1.0, dt, sj, 3, 0.5)
+    with pytest.raises(ValueError):
+        pycwt_amd.significance(1.0, dt, sj, 2, 0.5, dof=[2, 8], wavelet=pycwt_amd.Morlet(5))
+
+
+def test_xwt(emulated, g):
+    W12, coi, freq, signif = pycwt_amd.xwt(g["y1"], g["y2"], float(g["dt"]), float(g["dj"]), -1, -1, 0.95,
+                                           pycwt_amd.Morlet(6), True)
+    assert W12.shape == g["xwt_W12"].shape
+    assert np.abs(W12 - g["xwt_W12"]).max() < 1e-11 * np.abs(g["xwt_W12"]).max()
+    np.testing.assert_allclose(coi, g["xwt_coi"], rtol=1e-14)
+    np.testing.assert_allclose(freq, g["xwt_freq"], rtol=1e-14)
+    np.testing.assert_allclose(signif, g["xwt_signif"], rtol=1e-12)
+    W12u, _, _, sigu = pycwt_amd.xwt(g["y1"], g["y2"], float(g["dt"]), float(g["dj"]), significance_level=0.9,
+                                     normalize=False)
+    assert np.abs(W12u - g["xwt_W12_unnorm"]).max() < 1e-11 * np.abs(g["xwt_W12_unnorm"]).max()
+    np.testing.assert_allclose(sigu, g["xwt_signif_unnorm"], rtol=1e-12)
+
+
+def test_morlet_smooth_complex_and_real(emulated, g):
+    m = pycwt_amd.Morlet(6)
+    dt, dj, sj = float(g["dt"]), float(g["dj"]), g["sj"]
+    W = pycwt_amd.cwt(g["y1"], dt, dj, -1, -1, m)[0]
+    sc = m.smooth(W / sj[:, None], dt, dj, sj)
+    assert np.iscomplexobj(sc) and np.abs(sc - g["smooth_complex"]).max() < 1e-12 * np.abs(g["smooth_complex"]).max()
+    sr = m.smooth(np.abs(W) ** 2 / sj[:, None], dt, dj, sj)
+    assert not np.iscomplexobj(sr)
+    assert np.abs(sr - g["smooth_real"]).max() < 1e-12 * np.abs(g["smooth_real"]).max()
+
+
+def test_wct_without_monte_carlo(emulated, g):
+    WCT, aWCT, coi, freq, sig = pycwt_amd.wct(g["y1"], g["y2"], float(g["dt"]), float(g["dj"]), -1, -1, False,
+                                              0.95, pycwt_amd.Morlet(6), True)
+    assert WCT.shape == g["wct"].shape and WCT.dtype == np.float64
+    assert np.abs(WCT - g["wct"]).max() < 1e-10
+    d = np.angle(np.exp(1j * (aWCT - g["awct"])))
+    assert np.abs(d).max() < 1e-9
+    np.testing.assert_allclose(coi, g["wct_coi"], rtol=1e-14)
+    np.testing.assert_allclose(freq, g["wct_freq"], rtol=1e-14)
+    assert sig.shape == (1,) and sig[0] == 0
+    assert WCT.min() >= 0 and WCT.max() <= 1 + 1e-12
+    with pytest.raises(AttributeError):                # only Morlet defines smooth (mothers.py:61)
+        pycwt_amd.wct(g["y1"], g["y2"], 0.5, wavelet="paul", sig=False)
+
+
+def test_wct_significance_monte_carlo_small(emulated, tmp_path, monkeypatch):
+    """Statistical check of the Monte-Carlo path on a tiny problem + cache round trip."""
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "get_cache_dir", lambda: str(tmp_path) + "/")
+    np.random.seed(3)
+    kw = dict(dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=12, progress=False, wavelet="morlet")
+    sig = pycwt_amd.wct_significance(0.3, 0.5, **kw)
+    assert sig.shape == (7,)
+    finite = np.isfinite(sig)
+    assert finite.any() and (sig[finite] > 0.3).all() and (sig[finite] <= 1).all()
+    again = pycwt_amd.wct_significance(0.3, 0.5, **kw)          # served from the cache file
+    np.testing.assert_allclose(again, sig, equal_nan=True)
+    assert len(list(tmp_path.glob("wct_sig_*_Morlet.gz"))) == 1

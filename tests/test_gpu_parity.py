@@ -229,3 +229,52 @@ def test_plan_rejects_lengths_beyond_limit(hip_library):
         _hip.Plan(1 << 25, 64, max_rows=1)
     with pytest.raises(_hip.HipError, match="power of two"):
         _hip.Plan(3000, 64, max_rows=1)
+
+
+# ---- callers of the hot path on the device ------------------------------
+def test_callers_against_reference_fixture(hip_library):
+    g = load_golden("callers")
+    dt, dj, sj = float(g["dt"]), float(g["dj"]), g["sj"]
+    m = pycwt_amd.Morlet(6)
+    W12, coi, freq, signif = pycwt_amd.xwt(g["y1"], g["y2"], dt, dj, -1, -1, 0.95, m, True)
+    assert np.abs(W12 - g["xwt_W12"]).max() < 1e-11 * np.abs(g["xwt_W12"]).max()
+    np.testing.assert_allclose(signif, g["xwt_signif"], rtol=1e-12)
+    W = pycwt_amd.cwt(g["y1"], dt, dj, -1, -1, m)[0]
+    sc = m.smooth(W / sj[:, None], dt, dj, sj)
+    assert np.abs(sc - g["smooth_complex"]).max() < 1e-12 * np.abs(g["smooth_complex"]).max()
+    sr = m.smooth(np.abs(W) ** 2 / sj[:, None], dt, dj, sj)
+    assert not np.iscomplexobj(sr) and np.abs(sr - g["smooth_real"]).max() < 1e-12 * np.abs(g["smooth_real"]).max()
+    WCT, aWCT, coi, freq, sig = pycwt_amd.wct(g["y1"], g["y2"], dt, dj, -1, -1, False, 0.95, m, True)
+    assert np.abs(WCT - g["wct"]).max() < 1e-10
+    assert np.abs(np.angle(np.exp(1j * (aWCT - g["awct"])))).max() < 1e-9
+    for prec, tol in ((32, 2e-3),):
+        WCT32 = pycwt_amd.wct(g["y1"], g["y2"], dt, dj, sig=False, precision=prec)[0]
+        assert np.abs(WCT32 - g["wct"]).max() < tol
+
+
+def test_coherence_properties_long_series(hip_library):
+    """N = 2^16: coherence of a series with itself is 1, with a scaled+delayed copy stays ~1 and the
+    phase tracks the delay; smoothing on the two-pass/band-limited paths (per-row spectra)."""
+    n = 1 << 16
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(n)
+    WCT, aWCT, coi, freq, _ = pycwt_amd.wct(x, x, 1.0, 1.0, sig=False)
+    assert np.abs(WCT - 1).max() < 1e-9 and np.abs(aWCT).max() < 1e-9
+    y = 3.0 * np.roll(x, 5)
+    WCT, aWCT, coi, freq, _ = pycwt_amd.wct(x, y, 1.0, 1.0, sig=False)
+    inner = slice(n // 4, 3 * n // 4)
+    assert WCT[6:, inner].min() > 0.97
+    j = 8                                              # period = 1/freq[j]; a delay of 5 samples is a phase of 2*pi*5*f
+    expect = 2 * np.pi * 5 * freq[j]
+    assert abs(np.median(aWCT[j, inner]) - expect) < 0.05 * max(1.0, expect)
+
+
+def test_wct_significance_gpu(hip_library, tmp_path, monkeypatch):
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "get_cache_dir", lambda: str(tmp_path) + "/")
+    np.random.seed(1)
+    sig = pycwt_amd.wct_significance(0.6, 0.4, dt=0.5, dj=0.25, s0=1.0, J=20, mc_count=40, progress=False)
+    ok = np.isfinite(sig)
+    assert ok.sum() >= 10 and (sig[ok] > 0.5).all() and (sig[ok] < 1).all()
+    # the 95 % coherence level of red noise grows only mildly with scale (Grinsted et al. 2004, fig. 3)
+    assert sig[ok].max() - sig[ok].min() < 0.4
