@@ -103,6 +103,15 @@ int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double 
                        const double* scales_host, int nrows, void* W_dev, int64_t ldw,
                        int64_t ncols);
 
+/* Same transform for a mother wavelet that only exists as a Python object (the reference's
+ * duck-typed protocol, mothers.py): the host evaluates psi_ft_bar = sqrt(s*w1*N)*conj(psi_ft(s*w)) as
+ * wavelet.py:102-104 does and hands the filter bank over explicitly.
+ * table_dev: nrows x nfft complex, row j = F_j[k] in FFT order; k_lo/nband: signed-bin support of
+ * each row (k_lo >= -nfft/2, k_lo + nband <= nfft/2; bins outside are taken as exactly zero).       */
+int cwt_transform_rows_table(cwt_plan* plan, const void* xhat_dev, const void* table_dev,
+                             const int* k_lo_host, const int* nband_host, int nrows, void* W_dev,
+                             int64_t ldw, int64_t ncols);
+
 /* ---- building blocks of the callers of cwt (next rows of the hot-path table: Morlet.smooth,
  * xwt, wct).  All device resident, queued on the plan's stream.
  *

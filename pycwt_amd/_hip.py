@@ -34,6 +34,8 @@ SYMBOLS = [
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_transform_rows_table", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P,
+                                           C.c_int64, C.c_int64]),
     ("cwt_fft_rows", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
     ("cwt_filter_rows", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
@@ -142,6 +144,13 @@ class Plan:
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
+
+    def transform_rows_table(self, xhat_dev: int, table_dev: int, k_lo, nband, W_dev: int, ldw: int, ncols: int):
+        k = np.ascontiguousarray(k_lo, dtype=np.int32)
+        b = np.ascontiguousarray(nband, dtype=np.int32)
+        self.lib.check(self.lib.cwt_transform_rows_table(
+            self.h, _P(xhat_dev), _P(table_dev), k.ctypes.data_as(C.POINTER(C.c_int)),
+            b.ctypes.data_as(C.POINTER(C.c_int)), k.size, _P(W_dev), ldw, ncols))
 
     def fft_rows(self, in_dev: int, in_complex: bool, nrows: int, in_ld: int, ncols_in: int, spec_dev: int):
         self.lib.check(self.lib.cwt_fft_rows(self.h, _P(in_dev), int(in_complex), nrows, in_ld, ncols_in,

@@ -237,10 +237,12 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
 // Row table for W[j,:] = IFFT_N( spec_j[k] * (amp_j * profile(a_j * signed_bin(k))) ), spec_j = spec + j*spec_ld.
 // a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
 int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
-                    const double* amp_im, int64_t spec_ld, int nrows) {
+                    const double* amp_im, int64_t spec_ld, int nrows, const int* tab_klo = nullptr,
+                    const int* tab_nband = nullptr) {
   const int64_t N = p->N;
-  double f_lo, f_hi;
-  if (mother < MOTHER_MORLET || mother > MOTHER_DOG) return fail(CWT_EINVAL, "unknown mother id");
+  double f_lo = 0, f_hi = 0;
+  if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
+  if (mother != MOTHER_TABLE)
   profile_support(mother, param, p->prec == 64 ? 1e-18 : 1e-9, &f_lo, &f_hi);
 
   const int logP = std::min(p->log_wg_points, p->logN);
@@ -257,11 +259,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.amp_re = amp_re[j] / double(N);
     rd.amp_im = amp_im[j] / double(N);
     rd.spec_off = long(spec_ld) * j;
+    rd.tab_off = long(N) * j;
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
     klo = std::max(klo, -double(N / 2));
     khi = std::min(khi, double(N / 2 - 1));
-    if (N == 1) { klo = 0; khi = 0; }
+    if (mother == MOTHER_TABLE) { klo = tab_klo[j]; khi = klo + tab_nband[j] - 1; }
+    if (khi < klo - 1) khi = klo - 1;
+    if (klo < -double(N / 2) || khi > double(N / 2 - 1)) return fail(CWT_EINVAL, "filter support outside [-N/2, N/2)");
     rd.k_lo = int(klo);
     rd.nband = khi >= klo ? int(khi - klo + 1) : 0;
     if (rd.nband == 0) rd.k_lo = 0;
@@ -381,7 +386,7 @@ bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>*
 template <typename T, int MODE>
 int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int64_t n0, void* out_dev) {
   const int logN = p->logN;
-  const Mother mo{MOTHER_MORLET, 0, 0.0};
+  const Mother mo{MOTHER_MORLET, 0, 0.0, nullptr};
   cplx<T>* out = static_cast<cplx<T>*>(out_dev);
   if (logN <= 3) {
     const int total = nrows << logN;
@@ -742,7 +747,25 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
   }
   p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
   Mother mo;
-  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
+  return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
+                       : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
+}
+
+int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* table_dev, const int* k_lo,
+                             const int* nband, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
+  if (!p || !xhat_dev || !table_dev || !k_lo || !nband || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
+  if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
+  HIPCHECK(hipSetDevice(p->device));
+  p->table_valid = false;
+  std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
+  int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
+  if (!rc) rc = run_filter_rows(p, xhat_dev, MOTHER_TABLE, 0.0, nrows, W_dev, ldw, ncols);
+  if (rc) return rc;
+  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  Mother mo;
+  mo.kind = MOTHER_TABLE; mo.m = 0; mo.p = 0; mo.table = table_dev;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
 }
@@ -776,7 +799,7 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (rc) return rc;
   p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
   Mother mo;
-  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, spec_dev, mo, nrows, W_dev, ldw, ncols)
                        : rows_impl<float>(p, spec_dev, mo, nrows, W_dev, ldw, ncols);
 }

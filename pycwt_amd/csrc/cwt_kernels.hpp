@@ -22,7 +22,7 @@
 #endif
 namespace cwt {
 
-enum : int { MOTHER_MORLET = 0, MOTHER_PAUL = 1, MOTHER_DOG = 2 };
+enum : int { MOTHER_MORLET = 0, MOTHER_PAUL = 1, MOTHER_DOG = 2, MOTHER_TABLE = 3 };
 enum : int { IN_SPECTRUM = 0, IN_REAL = 1, IN_CPLX = 2 };   // IN_CPLX: complex rows, conjugated on load
 
 // One row (scale) of the transform, prepared on the host in double precision.
@@ -36,12 +36,14 @@ struct RowDesc {
   int logK;        // k_narrow: log2 of this row's FFT length
   int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
   long spec_off;   // element offset of this row's spectrum (0: all rows share one spectrum)
+  long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N)
 };
 
 struct Mother {
-  int kind;    // MOTHER_*
-  int m;       // integer order for Paul / DOG
-  double p;    // f0 (Morlet) or m
+  int kind;           // MOTHER_*
+  int m;              // integer order for Paul / DOG
+  double p;           // f0 (Morlet) or m
+  const void* table;  // MOTHER_TABLE: rows x N complex filter bank on the device (custom mothers)
 };
 
 // Tables for e^{2 pi i t / N}, t < N, as a product of a coarse and a fine root of unity.
@@ -111,8 +113,13 @@ __device__ __forceinline__ cplx<T> filtered_bin(const cplx<T>* __restrict__ xhat
                                                 const Mother& mo, int ks, int nmask) {
   const unsigned d = unsigned(ks - rd.k_lo);
   if (d >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
-  const T g = profile<T>(mo, T(rd.a) * T(ks));
   const cplx<T> x = (xhat + rd.spec_off)[ks & nmask];
+  if (mo.kind == MOTHER_TABLE) {   // explicit filter bank: F_j[k] was evaluated by the host from psi_ft
+    const cplx<T> f = (static_cast<const cplx<T>*>(mo.table) + rd.tab_off)[ks & nmask];
+    const T s = T(rd.amp_re);
+    return mk<T>((x.x * f.x - x.y * f.y) * s, (x.x * f.y + x.y * f.x) * s);
+  }
+  const T g = profile<T>(mo, T(rd.a) * T(ks));
   const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
   return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
 }
@@ -157,7 +164,7 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
     RowDesc rd;
-    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; }
+    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = g.j + (e << logNT);

@@ -72,6 +72,42 @@ def _nan_rows(mother, sj, N, dt):
     return bad
 
 
+def _cwt_with_host_filter_bank(x, dt, sj, mother, N, precision, device):
+    """Any duck-typed mother (only `psi_ft`, `flambda`, `coi` needed, as in the reference): the filter
+    bank of wavelet.py:102-104 is evaluated with NumPy exactly as the reference does and handed to the
+    engine as an explicit table; FFTs, multiply and the band-limited / two-pass machinery stay on the
+    GPU.  Returns (W, xhat, keep-mask or None)."""
+    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
+    with np.errstate(all="ignore"):
+        bank = (sj[:, None] * ftfreqs[1] * N) ** .5 * np.conjugate(mother.psi_ft(sj[:, None] * ftfreqs))
+    bank = np.asarray(bank, dtype=np.complex128) * np.ones((1, N))
+    bad = np.isnan(bank).any(axis=1)                        # a NaN bin makes the whole row NaN (:111-115)
+    keep = None
+    if bad.any() and not bad.all():
+        keep = ~bad
+        bank, sj = bank[keep], sj[keep]
+    bank = np.nan_to_num(bank)
+    rows = sj.size
+    mag = np.fft.fftshift(np.abs(bank), axes=1)             # signed-bin order: -N/2 .. N/2-1
+    live = mag > (1e-18 if precision == 64 else 1e-9) * np.maximum(mag.max(axis=1, keepdims=True), 1e-300)
+    first = np.where(live.any(axis=1), live.argmax(axis=1), 0)
+    last = np.where(live.any(axis=1), N - 1 - live[:, ::-1].argmax(axis=1), -1)
+    k_lo, nband = first - N // 2, np.maximum(last - first + 1, 0)
+    plan = _plan(N, precision, device, rows)
+    es = np.dtype(plan.real).itemsize
+    sc = _Scratch(device)
+    try:
+        xd, xh = sc.new(x.size * es), sc.new(N * 2 * es)
+        tab, Wd = sc.new(rows * N * 2 * es), sc.new(rows * x.size * 2 * es)
+        xd.upload(plan, x)
+        tab.upload(plan, np.ascontiguousarray(bank, dtype=plan.cplx))
+        plan.forward_fft(xd.ptr, x.size, xh.ptr)
+        plan.transform_rows_table(xh.ptr, tab.ptr, k_lo, nband, Wd.ptr, x.size, x.size)
+        return Wd.download(plan, (rows, x.size), plan.cplx), xh.download(plan, (N,), plan.cplx), keep
+    finally:
+        sc.free()
+
+
 def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
         device=0):
     """Continuous wavelet transform; drop-in for ``pycwt.cwt`` (wavelet.py:13-124).
@@ -95,16 +131,22 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
     sj = np.asarray(sj, dtype=np.float64)
 
     N = _next_pow2(n0)
-    bad = _nan_rows(mother, sj, N, dt)
-    if bad.any() and not bad.all():                     # wavelet.py:111-115
-        keep = ~bad
-        sj = sj[keep]
-        freqs = np.asarray(freqs)[keep]
-
-    kind, param = _device_id(mother)
-    plan = _plan(N, precision, device, sj.size)
     real = np.float64 if precision == 64 else np.float32
-    W, xhat = plan.execute_host(np.asarray(signal, dtype=real), kind, param, dt, sj)
+    if hasattr(mother, "device_id"):
+        bad = _nan_rows(mother, sj, N, dt)
+        if bad.any() and not bad.all():                     # wavelet.py:111-115
+            keep = ~bad
+            sj = sj[keep]
+            freqs = np.asarray(freqs)[keep]
+        kind, param = mother.device_id()
+        plan = _plan(N, precision, device, sj.size)
+        W, xhat = plan.execute_host(np.asarray(signal, dtype=real), kind, param, dt, sj)
+    else:
+        W, xhat, keep = _cwt_with_host_filter_bank(np.asarray(signal, dtype=real), dt, sj, mother, N, precision,
+                                                   device)
+        if keep is not None:
+            sj = sj[keep]
+            freqs = np.asarray(freqs)[keep]
     if W.dtype != np.complex128:
         W = W.astype(np.complex128)
         xhat = xhat.astype(np.complex128)
