@@ -258,7 +258,7 @@ __device__ __forceinline__ void wg_ifft(T (&re)[16], T (&im)[16], T* lds, const 
 //   ROWS  : a = t*L + pos, physical index a + (a >> 4)  (one pad element per 16): the stride-16
 //           Stockham writes become stride 17, and all offsets stay additive because every
 //           stride used is a multiple of 16 elements.  Requires L >= 256.
-// Synchronisation: PLANES -> workgroup barriers.  ROWS with one FFT per wavefront (L = 1024) ->
+// Synchronisation: PLANES -> workgroup barriers.  ROWS with every FFT inside one wavefront (L <= 1024) ->
 // no s_barrier at all: LDS operations of one wave execute in order, so a compiler-level fence is
 // enough between the write and the read phase.
 namespace ct {
@@ -273,7 +273,7 @@ template <typename T, int LOGL, int LOGTB, bool PLANES>
 struct Fft {
   static constexpr int L = 1 << LOGL, TB = 1 << LOGTB, LOGNT = LOGL - 4, NT = 1 << LOGNT;
   static constexpr int NFULL = LOGL / 4, REM = LOGL % 4;
-  static constexpr bool WAVE_LOCAL = !PLANES && NT == 64;   // one FFT == one wavefront
+  static constexpr bool WAVE_LOCAL = !PLANES && NT <= 64;   // every FFT lives inside one wavefront
   static_assert(PLANES || LOGL >= 8, "ROWS layout needs L >= 256");
   static constexpr int LDS_ELEMS = PLANES ? (TB * L) : (TB * L + ((TB * L) >> 4));
 

@@ -42,6 +42,27 @@ __global__ void k_seg(double2* W, int logN, int logK, double v) {
   for (int m = j; m < K; m += NT) row[(size_t(m) << logR) + r0 + t] = make_double2(v + m, v - t);
 }
 
+// "one FFT per wavefront" store pattern: wave w of the workgroup owns residue r0 + w, lane l slot e owns
+// output m = l + 64 e: every store instruction writes 64 separate 16-B pieces; the neighbouring pieces
+// of each 128-B line come from the other 7 waves of the SAME workgroup (same CU, same L2).
+__global__ void k_seg_wave(double2* W, int logN, int logK, double v) {
+  const int logR = logN - logK;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const size_t r = (size_t(blockIdx.x) << 3) + w;
+  double2* row = W + (size_t(blockIdx.y) << logN);
+  const int K = 1 << logK;
+  for (int m = l; m < K; m += 64) row[(size_t(m) << logR) + r] = make_double2(v + m, v - w);
+}
+// same, but the 8 waves are made to run ~in lockstep by a barrier per store round
+__global__ void k_seg_wave_sync(double2* W, int logN, int logK, double v) {
+  const int logR = logN - logK;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const size_t r = (size_t(blockIdx.x) << 3) + w;
+  double2* row = W + (size_t(blockIdx.y) << logN);
+  const int K = 1 << logK;
+  for (int m = l; m < K; m += 64) { row[(size_t(m) << logR) + r] = make_double2(v + m, v - w); __syncthreads(); }
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main() {
@@ -77,6 +98,8 @@ int main() {
     snprintf(nm, 64, "seg T=64 (1KiB) K=2^%d", logK);
     bench(nm, n * 16.0, [&] { hipLaunchKernelGGL(k_seg<6>, dim3(N >> (logK + 6), rows), dim3(512), 0, 0, A, int(logN), logK, 1.0); });
   }
+  bench("seg per-wave 16B pieces K=2^10", n * 16.0, [&] { hipLaunchKernelGGL(k_seg_wave, dim3(N >> (10 + 3), rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg per-wave 16B + barrier", n * 16.0, [&] { hipLaunchKernelGGL(k_seg_wave_sync, dim3(N >> (10 + 3), rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
   // write S MiB then read it back; time of the read only (events around the read), min of 5
   printf("write-then-read (time of the read kernel only):\n");
   for (size_t mib : {16, 32, 64, 128, 192, 256, 512, 1024}) {
