@@ -63,7 +63,8 @@ int cwt_plan_destroy(cwt_plan* plan);
 /* hipStream_t handle (as void*) all later launches of this plan are queued on. */
 int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
 /* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  Keys:
- *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex)
+ *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex); 0 = default:
+ *                  as many rows as fit 192 MiB, so that the intermediate stays in the Infinity Cache
  *   "narrow"       0 disables the band-limited single-pass path
  *   "narrow_max_k" largest per-row transform length of that path (power of two)
  *   "lmax"         largest single-workgroup FFT length (power of two, <= 4096)
@@ -102,6 +103,15 @@ int cwt_forward_fft(cwt_plan* plan, const void* x_dev, int64_t n0, void* xhat_de
 int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double param, double dt,
                        const double* scales_host, int nrows, void* W_dev, int64_t ldw,
                        int64_t ncols);
+
+/* Batch of equally long signals sharing one scale grid (BASELINE config 4): xhat_dev holds nbatch
+ * spectra (signal b at xhat_dev + b*xhat_ld, e.g. written by cwt_fft_rows), W_dev is
+ * nbatch x nrows x ldw: W[b, j, :] = row j of signal b.  One set of launches covers the whole batch
+ * (the row table simply has nbatch*nrows entries), so short series still fill the GPU.
+ * Needs nbatch*nrows <= max_rows of the plan.                                                      */
+int cwt_transform_rows_batch(cwt_plan* plan, const void* xhat_dev, int nbatch, int64_t xhat_ld,
+                             int mother, double param, double dt, const double* scales_host,
+                             int nrows, void* W_dev, int64_t ldw, int64_t ncols);
 
 /* Same transform for a mother wavelet that only exists as a Python object (the reference's
  * duck-typed protocol, mothers.py): the host evaluates psi_ft_bar = sqrt(s*w1*N)*conj(psi_ft(s*w)) as

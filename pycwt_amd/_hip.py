@@ -34,6 +34,8 @@ SYMBOLS = [
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_transform_rows_batch", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double,
+                                           C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
     ("cwt_transform_rows_table", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P,
                                            C.c_int64, C.c_int64]),
     ("cwt_fft_rows", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
@@ -144,6 +146,13 @@ class Plan:
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
+
+    def transform_rows_batch(self, xhat_dev: int, nbatch: int, xhat_ld: int, mother: int, param: float,
+                             dt: float, scales, W_dev: int, ldw: int, ncols: int):
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_transform_rows_batch(self.h, _P(xhat_dev), nbatch, xhat_ld, mother,
+                                                         float(param), float(dt), _dptr(s), s.size, _P(W_dev),
+                                                         ldw, ncols))
 
     def transform_rows_table(self, xhat_dev: int, table_dev: int, k_lo, nband, W_dev: int, ldw: int, ncols: int):
         k = np.ascontiguousarray(k_lo, dtype=np.int32)

@@ -58,7 +58,8 @@ struct cwt_plan {
   int max_rows = 0;
   hipStream_t stream = nullptr;
   // options
-  int chunk_rows = 12;     // 12 x 16 MiB (N = 2^20, fp64) of intermediate stays inside the 256 MiB Infinity Cache
+  int chunk_rows = 0;      // rows per two-pass chunk; 0 = as many as fit 192 MiB of intermediate, which
+                           // stays inside the 256 MiB Infinity Cache (12 rows at N = 2^20 fp64)
   int narrow = 1;
   int narrow_max_logk = 10;
   int loglmax = 12;
@@ -238,7 +239,7 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
 // a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
 int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
                     const double* amp_im, int64_t spec_ld, int nrows, const int* tab_klo = nullptr,
-                    const int* tab_nband = nullptr) {
+                    const int* tab_nband = nullptr, int rows_per_signal = 0) {
   const int64_t N = p->N;
   double f_lo = 0, f_hi = 0;
   if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
@@ -258,7 +259,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.a = a[j];
     rd.amp_re = amp_re[j] / double(N);
     rd.amp_im = amp_im[j] / double(N);
-    rd.spec_off = long(spec_ld) * j;
+    // batched signals: row j belongs to signal j / rows_per_signal, whose spectrum starts at spec_ld * that
+    rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
     rd.tab_off = long(N) * j;
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
@@ -312,6 +314,12 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
 }
 
 // log2 of the row length K of the two-pass factorisation N = R*K
+int chunk_rows_of(const cwt_plan* p) {
+  if (p->chunk_rows > 0) return p->chunk_rows;
+  const size_t row_bytes = size_t(p->N) * 2 * p->esize();
+  return int(std::max<size_t>(1, (size_t(192) << 20) / row_bytes));
+}
+
 int two_pass_logk(const cwt_plan* p) {
   int lk = std::min(10, p->logN - 4);
   lk = std::max(lk, p->logN - p->loglmax);
@@ -409,7 +417,7 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   }
   const int logK = two_pass_logk(p), logR = logN - logK;
   const int logP = std::min(p->log_wg_points, logN);
-  const int chunk = std::max(1, std::min(p->chunk_rows, nrows));
+  const int chunk = std::max(1, std::min(chunk_rows_of(p), nrows));
   int rc = ensure_z(p, chunk);
   if (rc) return rc;
   const size_t lds = (size_t(1) << logP) * sizeof(T);
@@ -470,7 +478,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   if (p->n_wide) {
     const int logK = two_pass_logk(p), logR = logN - logK;
-    const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));
+    const int chunk = std::max(1, std::min(chunk_rows_of(p), p->n_wide));
     const int nchunks = (p->n_wide + chunk - 1) / chunk;
     const bool pipelined = p->overlap && nchunks > 1;
     rc = ensure_z(p, pipelined ? 2 * chunk : chunk);
@@ -525,7 +533,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     }
   }
   if (p->n_wide) {
-    const int chunk = std::max(1, std::min(p->chunk_rows, p->n_wide));
+    const int chunk = std::max(1, std::min(chunk_rows_of(p), p->n_wide));
     const int nchunks = (p->n_wide + chunk - 1) / chunk;
     if (p->overlap && nchunks > 1) {   // join: every pass A is followed by its pass B on side stream 1
       HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
@@ -650,7 +658,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
   p->table_valid = false;
-  if (k == "chunk_rows") { if (value < 1) return fail(CWT_EINVAL, "chunk_rows >= 1"); p->chunk_rows = int(value); }
+  if (k == "chunk_rows") { if (value < 0) return fail(CWT_EINVAL, "chunk_rows >= 0"); p->chunk_rows = int(value); }
   else if (k == "narrow") p->narrow = value != 0;
   else if (k == "narrow_max_k") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "narrow_max_k: power of two in [16,4096]"); p->narrow_max_logk = ilog2(value); }
   else if (k == "lmax") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "lmax: power of two in [16,4096]"); p->loglmax = ilog2(value); }
@@ -750,6 +758,42 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
+}
+
+int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int64_t xhat_ld, int mother,
+                             double param, double dt, const double* scales, int nrows, void* W_dev,
+                             int64_t ldw, int64_t ncols) {
+  if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nbatch < 1 || nrows < 1 || int64_t(nbatch) * nrows > p->max_rows)
+    return fail(CWT_EINVAL, "need nbatch*nrows <= max_rows");
+  if (xhat_ld < p->N) return fail(CWT_EINVAL, "xhat_ld must be >= nfft");
+  if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
+  if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
+  HIPCHECK(hipSetDevice(p->device));
+  p->table_valid = false;
+  double cre, cim;
+  int rc = mother_constant(mother, param, &cre, &cim);
+  if (rc) return rc;
+  const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(p->N) * dt));
+  const int total = nbatch * nrows;
+  std::vector<double> a(total), ar(total), ai(total);
+  for (int j = 0; j < total; ++j) {
+    const double s = scales[j % nrows];
+    if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
+    a[j] = s * w1;
+    const double norm = std::sqrt(s * w1 * double(p->N));
+    ar[j] = norm * cre;
+    ai[j] = norm * cim;
+  }
+  // W is treated as one (nbatch*nrows) x ldw matrix: row b*nrows + j = scale j of signal b
+  rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), xhat_ld, total, nullptr, nullptr, nrows);
+  if (!rc) rc = run_filter_rows(p, xhat_dev, mother, param, total, W_dev, ldw, ncols);
+  if (rc) return rc;
+  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  Mother mo;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
+  return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols)
+                       : rows_impl<float>(p, xhat_dev, mo, total, W_dev, ldw, ncols);
 }
 
 int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* table_dev, const int* k_lo,

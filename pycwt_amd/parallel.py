@@ -36,10 +36,19 @@ class HipEngine:
         self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
 
     def forward(self, x, n0, xhat):
-        self.plan.forward_fft(x.data_ptr(), n0, xhat.data_ptr())
+        """x: (n0,) or (batch, n0) reals -> xhat: (N,) or (batch, N) spectra."""
+        if x.dim() == 1:
+            self.plan.forward_fft(x.data_ptr(), n0, xhat.data_ptr())
+        else:
+            self.plan.fft_rows(x.data_ptr(), False, x.shape[0], x.shape[1], n0, xhat.data_ptr())
 
     def rows(self, xhat, kind, param, dt, sj, W, ncols):
-        self.plan.transform_rows(xhat.data_ptr(), kind, param, dt, sj, W.data_ptr(), W.shape[1], ncols)
+        """W: (rows, n0) for one signal, (batch, rows, n0) for a batch."""
+        if xhat.dim() == 1:
+            self.plan.transform_rows(xhat.data_ptr(), kind, param, dt, sj, W.data_ptr(), W.shape[-1], ncols)
+        else:
+            self.plan.transform_rows_batch(xhat.data_ptr(), xhat.shape[0], xhat.shape[1], kind, param, dt, sj,
+                                           W.data_ptr(), W.shape[-1], ncols)
 
     def icwt_partial(self, W, sj, out):
         self.plan.icwt_reduce(W.data_ptr(), W.shape[1], W.shape[1], sj, 1.0, out.data_ptr())
@@ -48,6 +57,9 @@ class HipEngine:
 def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, group=None,
                 precision=64, device=None, engine=None, src=0):
     """Scale-sharded `cwt`.  Call on every rank of `group`; only rank `src` needs `signal`.
+
+    `signal` may be 2-D (batch x n0): then every rank transforms all signals for its scales and
+    `W_local` is (batch, len(rows_local), n0).
 
     Returns `(W_local, rows_local, sj, freqs, coi)`: `W_local` is a device tensor
     (len(rows_local) x n0, complex) holding rows `rows_local` of the full transform; `sj`, `freqs`,
@@ -65,11 +77,12 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
-    meta = [len(signal) if rank == src else None]
+    meta = [tuple(np.shape(signal)) if rank == src else None]
     if world > 1:
         dist.broadcast_object_list(meta, src=src, group=group)
-    n0 = int(meta[0])
-    x = torch.empty(n0, dtype=real_t, device=device)
+    shape = tuple(int(v) for v in meta[0])           # (n0,) or (batch, n0): BASELINE config 4
+    n0 = shape[-1]
+    x = torch.empty(shape, dtype=real_t, device=device)
     if rank == src:
         x.copy_(torch.as_tensor(np.asarray(signal), dtype=real_t))
     if world > 1:
@@ -94,10 +107,11 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
 
     mine = shard_rows(sj.size, world, rank)
     kind, param = _device_id(mother)
+    nbatch = shape[0] if len(shape) == 2 else 1
     if engine is None:
-        engine = HipEngine(N, precision, max(1, mine.size), device.index or 0)
-    xhat = torch.empty(N, dtype=cplx_t, device=device)
-    W = torch.empty((mine.size, n0), dtype=cplx_t, device=device)
+        engine = HipEngine(N, precision, max(1, mine.size * nbatch), device.index or 0)
+    xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
+    W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
     engine.forward(x, n0, xhat)
     if mine.size:
         engine.rows(xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)

@@ -157,6 +157,58 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
     return (W, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
 
 
+def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
+              device=0, max_batch_bytes=8 << 30):
+    """`cwt` of a batch of equally long signals (2-D array, one signal per row) with one scale grid --
+    an extension beyond the reference's 1-D `signal` (BASELINE config 4).
+
+    Returns `(W, sj, freqs, coi, fft, fftfreqs)` with `W` of shape (batch, rows, n0) and `fft` of shape
+    (batch, N//2 - 1); everything else as `cwt`.  The batch is pushed through the GPU in slabs of at
+    most `max_batch_bytes` of W; inside a slab every kernel launch covers all signals.
+    """
+    mother = _check_parameter_wavelet(wavelet)
+    precision = _default_precision() if precision is None else int(precision)
+    X = np.atleast_2d(np.asarray(signals))
+    nb, n0 = X.shape
+    if freqs is None:
+        if s0 == -1:
+            s0 = 2 * dt / mother.flambda()
+        if J == -1:
+            J = int(np.round(np.log2(n0 * dt / s0) / dj))
+        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+        freqs = 1 / (mother.flambda() * sj)
+    else:
+        sj = 1 / (mother.flambda() * freqs)
+    sj = np.asarray(sj, dtype=np.float64)
+    N = _next_pow2(n0)
+    bad = _nan_rows(mother, sj, N, dt)
+    if bad.any() and not bad.all():
+        sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
+    kind, param = _device_id(mother)
+    rows = sj.size
+    es = 8 if precision == 64 else 4
+    slab = int(max(1, min(nb, max_batch_bytes // (rows * n0 * 2 * es))))
+    plan = _plan(N, precision, device, slab * rows)
+    W = np.empty((nb, rows, n0), dtype=np.complex128)
+    xhat = np.empty((nb, N), dtype=np.complex128)
+    sc = _Scratch(device)
+    try:
+        xd, xh = sc.new(slab * n0 * es), sc.new(slab * N * 2 * es)
+        Wd = sc.new(slab * rows * n0 * 2 * es)
+        for b0 in range(0, nb, slab):
+            cnt = min(slab, nb - b0)
+            xd.upload(plan, np.ascontiguousarray(X[b0:b0 + cnt], dtype=plan.real))
+            plan.fft_rows(xd.ptr, False, cnt, n0, n0, xh.ptr)
+            plan.transform_rows_batch(xh.ptr, cnt, N, kind, param, dt, sj, Wd.ptr, n0, n0)
+            W[b0:b0 + cnt] = Wd.download(plan, (cnt, rows, n0), plan.cplx)
+            xhat[b0:b0 + cnt] = xh.download(plan, (cnt, N), plan.cplx)
+    finally:
+        sc.free()
+    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
+    return (W, sj, freqs, coi, xhat[:, 1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
+
+
 def icwt(W, sj, dt, dj=1 / 12, wavelet="morlet", *, precision=None, device=0):
     """Inverse transform, TC98 eq. 11; drop-in for ``pycwt.icwt`` (wavelet.py:127-171).
 

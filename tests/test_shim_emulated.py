@@ -139,3 +139,21 @@ def test_reference_mother_objects_are_accepted(emulated):
             per_row, _ = row_errors(out[0], out_ref[0])
             assert per_row.max() < 1e-12, m.name
             np.testing.assert_allclose(out[1], out_ref[1])
+
+
+@pytest.mark.parametrize("n0,nb,name", [(500, 5, "morlet"), (9000, 3, "dog"), (9000, 2, "paul")])
+def test_batch_of_signals_matches_loop_of_single_calls(emulated, n0, nb, name):
+    """BASELINE config 4 shape (many signals, one scale grid) at test size: the batched launch must equal
+    a Python loop of `cwt` calls (which is what a reference user would write)."""
+    X = np.random.default_rng(n0).standard_normal((nb, n0))
+    Wb, sj, freqs, coi, fftb, fftfreqs = pycwt_amd.cwt_batch(X, 0.5, 0.5, wavelet=name)
+    assert Wb.shape == (nb, sj.size, n0) and fftb.shape[0] == nb
+    for b in range(nb):
+        W1, sj1, freqs1, coi1, fft1, ff1 = pycwt_amd.cwt(X[b], 0.5, 0.5, wavelet=name)
+        per_row, _ = row_errors(Wb[b], W1)
+        assert per_row.max() < 1e-13
+        np.testing.assert_allclose(fftb[b], fft1, rtol=0, atol=1e-12 * np.abs(fft1).max())
+        np.testing.assert_allclose(sj, sj1)
+    # slabs smaller than the batch give the same result
+    Wb2 = pycwt_amd.cwt_batch(X, 0.5, 0.5, wavelet=name, max_batch_bytes=1)[0]
+    assert np.abs(Wb2 - Wb).max() == 0
