@@ -164,6 +164,17 @@ int cwt_wct_coherence(cwt_plan* plan, const void* S_dev, const void* S12_dev, in
 int cwt_icwt_reduce(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
                     const double* scales_host, double coeff, void* out_dev);
 
+/* Weighted reduction over scales with explicit weights:
+ *   out[n] = coeff * sum_j g(W[j, n]) * weights[j],  g = Re (power = 0) or |.|^2 (power = 1).
+ * power = 1 with weights 1/s_j on the selected scales (0 elsewhere) and coeff = dj*dt/cdelta is the
+ * scale-averaged power of TC98 eq. 24 (sample/simple_sample.py:87-91).  out_dev: ncols reals.       */
+int cwt_reduce_scales(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                      const double* weights_host, int power, double coeff, void* out_dev);
+/* Global wavelet spectrum: out[j] = mean_n |W[j, n]|^2 (power.mean(axis=1), simple_sample.py:79).
+ * out_dev: nrows reals.                                                                            */
+int cwt_time_mean_power(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                        void* out_dev);
+
 /* ---- host convenience: what the ctypes shim of pycwt.cwt() calls ---------
  * x_host: n0 reals of the plan's precision.  W_host: nrows x n0 complex (may be
  * NULL).  xhat_host: nfft complex (may be NULL) for the 5th return value

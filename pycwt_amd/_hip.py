@@ -46,6 +46,9 @@ SYMBOLS = [
     ("cwt_wct_coherence", C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int64, _P]),
     ("cwt_icwt_reduce", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double),
                                   C.c_double, _P]),
+    ("cwt_reduce_scales", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.c_int,
+                                    C.c_double, _P]),
+    ("cwt_time_mean_power", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _P]),
     ("cwt_execute_host", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    C.POINTER(C.c_double), C.c_int, _P, _P]),
     ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
@@ -190,6 +193,14 @@ class Plan:
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_icwt_reduce(self.h, _P(W_dev), ldw, ncols, s.size, _dptr(s),
                                                 float(coeff), _P(out_dev)))
+
+    def reduce_scales(self, W_dev: int, ldw: int, ncols: int, weights, power: bool, coeff: float, out_dev: int):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self.lib.check(self.lib.cwt_reduce_scales(self.h, _P(W_dev), ldw, ncols, w.size, _dptr(w), int(power),
+                                                  float(coeff), _P(out_dev)))
+
+    def time_mean_power(self, W_dev: int, ldw: int, ncols: int, nrows: int, out_dev: int):
+        self.lib.check(self.lib.cwt_time_mean_power(self.h, _P(W_dev), ldw, ncols, nrows, _P(out_dev)))
 
     # -- host convenience --
     def execute_host(self, x, mother: int, param: float, dt: float, scales, want_W=True, want_xhat=True):

@@ -927,32 +927,60 @@ int cwt_wct_coherence(cwt_plan* p, const void* S_dev, const void* S12_dev, int n
                        : coherence_impl<float>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev);
 }
 
-int cwt_icwt_reduce(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
-                    const double* scales, double coeff, void* out_dev) {
-  if (!p || !W_dev || !scales || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+extern "C++" {
+namespace {
+template <typename T, bool POWER>
+int reduce_scales_impl(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                       const double* weights, double coeff, void* out_dev) {
+  int rc = upload_reals<T>(p, weights, nrows);
+  if (rc) return rc;
+  const unsigned blocks = unsigned((ncols + 255) / 256);
+  return timed_launch(p, KC_ICWT, [&] {
+    hipLaunchKernelGGL((k_icwt<T, POWER>), dim3(blocks), dim3(256), 0, p->stream,
+                       static_cast<const cplx<T>*>(W_dev), long(ldw), long(ncols), nrows,
+                       static_cast<const T*>(p->weights_dev), T(coeff), static_cast<T*>(out_dev));
+  });
+}
+}  // namespace
+}  // extern "C++"
+
+int cwt_reduce_scales(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                      const double* weights, int power, double coeff, void* out_dev) {
+  if (!p || !W_dev || !weights || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "need ncols >= 1 and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  HIPCHECK(hipStreamSynchronize(p->stream));
+  if (p->prec == 64)
+    return power ? reduce_scales_impl<double, true>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev)
+                 : reduce_scales_impl<double, false>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev);
+  return power ? reduce_scales_impl<float, true>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev)
+               : reduce_scales_impl<float, false>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev);
+}
+
+int cwt_icwt_reduce(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
+                    const double* scales, double coeff, void* out_dev) {
+  if (!p || !scales) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
+  std::vector<double> w(nrows);
   for (int j = 0; j < nrows; ++j) {
     if (!(scales[j] > 0)) return fail(CWT_EINVAL, "scales must be positive");
-    const double w = 1.0 / std::sqrt(scales[j]);
-    if (p->prec == 64) static_cast<double*>(p->weights_pinned)[j] = w;
-    else static_cast<float*>(p->weights_pinned)[j] = float(w);
+    w[j] = 1.0 / std::sqrt(scales[j]);
   }
-  HIPCHECK(hipMemcpyAsync(p->weights_dev, p->weights_pinned, size_t(nrows) * p->esize(),
-                          hipMemcpyHostToDevice, p->stream));
-  const unsigned blocks = unsigned((ncols + 255) / 256);
+  return cwt_reduce_scales(p, W_dev, ldw, ncols, nrows, w.data(), 0, coeff, out_dev);
+}
+
+int cwt_time_mean_power(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols, int nrows, void* out_dev) {
+  if (!p || !W_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "bad shape");
+  HIPCHECK(hipSetDevice(p->device));
   if (p->prec == 64)
     return timed_launch(p, KC_ICWT, [&] {
-      hipLaunchKernelGGL((k_icwt<double>), dim3(blocks), dim3(256), 0, p->stream,
-                         static_cast<const double2*>(W_dev), long(ldw), long(ncols), nrows,
-                         static_cast<const double*>(p->weights_dev), coeff, static_cast<double*>(out_dev));
+      hipLaunchKernelGGL((k_time_mean<double>), dim3(nrows), dim3(256), 256 * sizeof(double), p->stream,
+                         static_cast<const double2*>(W_dev), long(ldw), long(ncols), static_cast<double*>(out_dev));
     });
   return timed_launch(p, KC_ICWT, [&] {
-    hipLaunchKernelGGL((k_icwt<float>), dim3(blocks), dim3(256), 0, p->stream,
-                       static_cast<const float2*>(W_dev), long(ldw), long(ncols), nrows,
-                       static_cast<const float*>(p->weights_dev), float(coeff), static_cast<float*>(out_dev));
+    hipLaunchKernelGGL((k_time_mean<float>), dim3(nrows), dim3(256), 256 * sizeof(double), p->stream,
+                       static_cast<const float2*>(W_dev), long(ldw), long(ncols), static_cast<float*>(out_dev));
   });
 }
 

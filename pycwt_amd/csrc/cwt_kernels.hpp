@@ -647,22 +647,49 @@ __global__ void k_wct_coherence(const cplx<T>* __restrict__ S, const cplx<T>* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_icwt: out[n] = coeff * sum_j Re W[j, n] * w[j],  w[j] = 1/sqrt(s_j)   (wavelet.py:169-170)
-template <typename T>
+// k_icwt: out[n] = coeff * sum_j g(W[j, n]) * w[j]; POWER = false: g = Re (TC98 eq. 11 with w = 1/sqrt(s_j),
+// wavelet.py:169-170); POWER = true: g = |.|^2 (scale-averaged power with w = 1/s_j on the selected scales,
+// TC98 eq. 24 as used in sample/simple_sample.py:87-91)
+template <typename T, bool POWER>
 __global__ void k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int nrows,
                        const T* __restrict__ w, T coeff, T* __restrict__ out) {
   const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
   if (n >= ncols) return;
-  T acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+  T acc[4] = {0, 0, 0, 0};
   int j = 0;
   for (; j + 4 <= nrows; j += 4) {
-    acc0 += W[long(j) * ldw + n].x * w[j];
-    acc1 += W[long(j + 1) * ldw + n].x * w[j + 1];
-    acc2 += W[long(j + 2) * ldw + n].x * w[j + 2];
-    acc3 += W[long(j + 3) * ldw + n].x * w[j + 3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const cplx<T> v = W[long(j + u) * ldw + n];
+      acc[u] += (POWER ? (v.x * v.x + v.y * v.y) : v.x) * w[j + u];
+    }
   }
-  for (; j < nrows; ++j) acc0 += W[long(j) * ldw + n].x * w[j];
-  out[n] = coeff * ((acc0 + acc1) + (acc2 + acc3));
+  for (; j < nrows; ++j) {
+    const cplx<T> v = W[long(j) * ldw + n];
+    acc[0] += (POWER ? (v.x * v.x + v.y * v.y) : v.x) * w[j];
+  }
+  out[n] = coeff * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
+// k_time_mean: out[j] = (1/ncols) sum_n |W[j, n]|^2  -- the global wavelet spectrum (power.mean(axis=1),
+// sample/simple_sample.py:79).  One workgroup of 256 threads per row, fp64 accumulation.
+template <typename T>
+__global__ void k_time_mean(const cplx<T>* __restrict__ W, long ldw, long ncols, T* __restrict__ out) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  double* part = reinterpret_cast<double*>(lds_raw);
+  const cplx<T>* row = W + long(blockIdx.x) * ldw;
+  double acc = 0;
+  for (long n = threadIdx.x; n < ncols; n += blockDim.x) {
+    const cplx<T> v = row[n];
+    acc += double(v.x) * double(v.x) + double(v.y) * double(v.y);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = T(part[0] / double(ncols));
 }
 
 }  // namespace cwt

@@ -157,6 +157,102 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
     return (W, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
 
 
+class DeviceTransform:
+    """A wavelet transform that stays on the GPU: W (rows x n0 complex) is device
+    resident; the reductions every caller of `cwt` does next -- power, global spectrum, scale
+    averages, reconstruction -- run there and only vectors cross PCIe.  `W()` downloads the matrix."""
+
+    def __init__(self, plan, buf, sj, freqs, coi, fft, fftfreqs, mother, dt, n0):
+        self._plan, self._buf = plan, buf
+        self.sj, self.freqs, self.coi, self.fft, self.fftfreqs = sj, freqs, coi, fft, fftfreqs
+        self.mother, self.dt, self.n0 = mother, dt, n0
+        self.shape = (sj.size, n0)
+
+    def close(self):
+        if self._buf is not None:
+            self._buf.free()
+            self._buf = None
+
+    __del__ = close
+
+    @property
+    def device_ptr(self):
+        return self._buf.ptr
+
+    def _vector(self, n, fill):
+        es = np.dtype(self._plan.real).itemsize
+        out = _hip.DeviceBuffer(n * es, self._plan.device)
+        try:
+            fill(out.ptr)
+            return out.download(self._plan, (n,), self._plan.real).astype(np.float64)
+        finally:
+            out.free()
+
+    def W(self):
+        return self._buf.download(self._plan, self.shape, self._plan.cplx).astype(np.complex128)
+
+    def global_power(self):
+        """mean over time of |W|^2 per scale (`power.mean(axis=1)`, sample/simple_sample.py:79)."""
+        rows, n0 = self.shape
+        return self._vector(rows, lambda p: self._plan.time_mean_power(self._buf.ptr, n0, n0, rows, p))
+
+    def scale_average(self, s1, s2, dj):
+        """Scale-averaged power over s1 <= s < s2: dj*dt/cdelta * sum_j |W_j|^2/s_j (TC98 eq. 24,
+        sample/simple_sample.py:85-91)."""
+        rows, n0 = self.shape
+        w = np.where((self.sj >= s1) & (self.sj < s2), 1.0 / self.sj, 0.0)
+        coeff = dj * self.dt / self.mother.cdelta
+        return self._vector(n0, lambda p: self._plan.reduce_scales(self._buf.ptr, n0, n0, w, True, coeff, p))
+
+    def icwt(self, dj):
+        """TC98 eq. 11 without leaving the device (wavelet.py:169-170)."""
+        rows, n0 = self.shape
+        total = self._vector(n0, lambda p: self._plan.icwt_reduce(self._buf.ptr, n0, n0, self.sj, 1.0, p))
+        return dj * np.sqrt(self.dt) / (self.mother.cdelta * self.mother.psi(0)) * total
+
+
+def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None, device=0):
+    """`cwt` whose result stays on the GPU: returns a `DeviceTransform` (attributes sj, freqs, coi, fft,
+    fftfreqs as in `cwt`; methods W(), global_power(), scale_average(), icwt())."""
+    mother = _check_parameter_wavelet(wavelet)
+    precision = _default_precision() if precision is None else int(precision)
+    n0 = len(signal)
+    if freqs is None:
+        if s0 == -1:
+            s0 = 2 * dt / mother.flambda()
+        if J == -1:
+            J = int(np.round(np.log2(n0 * dt / s0) / dj))
+        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+        freqs = 1 / (mother.flambda() * sj)
+    else:
+        sj = 1 / (mother.flambda() * freqs)
+    sj = np.asarray(sj, dtype=np.float64)
+    N = _next_pow2(n0)
+    bad = _nan_rows(mother, sj, N, dt)
+    if bad.any() and not bad.all():
+        sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
+    kind, param = _device_id(mother)
+    plan = _plan(N, precision, device, sj.size)
+    es = np.dtype(plan.real).itemsize
+    xd, xh = _hip.DeviceBuffer(n0 * es, device), _hip.DeviceBuffer(N * 2 * es, device)
+    Wd = _hip.DeviceBuffer(sj.size * n0 * 2 * es, device)
+    try:
+        xd.upload(plan, np.ascontiguousarray(signal, dtype=plan.real))
+        plan.forward_fft(xd.ptr, n0, xh.ptr)
+        plan.transform_rows(xh.ptr, kind, param, dt, sj, Wd.ptr, n0, n0)
+        xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
+    except Exception:
+        Wd.free()
+        raise
+    finally:
+        xd.free()
+        xh.free()
+    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
+    return DeviceTransform(plan, Wd, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi),
+                           mother, dt, n0)
+
+
 def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
               device=0, max_batch_bytes=8 << 30):
     """`cwt` of a batch of equally long signals (2-D array, one signal per row) with one scale grid --

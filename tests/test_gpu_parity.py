@@ -332,3 +332,23 @@ def test_config4_shape_batch_of_signals(hip_library):
     assert tuple(Wl.shape) == (nb, rows, n0)
     assert np.abs(Wl[3].cpu().numpy() - Wb[3]).max() == 0
     print(f"batch of {nb} x 2^16 x {rows}: {t_batch * 1e3:.1f} ms host wall incl. PCIe")
+
+
+def test_device_resident_workflow_on_gpu(hip_library):
+    """cwt_device + reductions (global spectrum, scale average, reconstruction) against NumPy on the
+    downloaded matrix, N = 2^18 so that all three transform paths contribute rows."""
+    n0 = (1 << 18) - 11
+    x = np.random.default_rng(18).standard_normal(n0)
+    dj = 0.25
+    T = pycwt_amd.cwt_device(x, 1.0, dj, wavelet="morlet")
+    W = T.W()
+    ref = orc.cwt_rows(x, 1.0, T.sj[[0, 20, 40, 60]], orc.Mother(orc.MORLET, 6))[:, :n0]
+    per_row, _ = row_errors(W[[0, 20, 40, 60]], ref)
+    assert per_row.max() < TOL[64]
+    power = np.abs(W) ** 2
+    np.testing.assert_allclose(T.global_power(), power.mean(axis=1), rtol=1e-10)
+    sel = (T.sj >= 4) & (T.sj < 64)
+    np.testing.assert_allclose(T.scale_average(4, 64, dj), dj / 0.776 * (power / T.sj[:, None])[sel].sum(axis=0),
+                               rtol=1e-10)
+    np.testing.assert_allclose(T.icwt(dj), orc.icwt(W, T.sj, 1.0, dj, "morlet"), rtol=1e-10, atol=1e-11)
+    T.close()

@@ -157,3 +157,26 @@ def test_batch_of_signals_matches_loop_of_single_calls(emulated, n0, nb, name):
     # slabs smaller than the batch give the same result
     Wb2 = pycwt_amd.cwt_batch(X, 0.5, 0.5, wavelet=name, max_batch_bytes=1)[0]
     assert np.abs(Wb2 - Wb).max() == 0
+
+
+def test_device_resident_transform_and_reductions(emulated):
+    """The canonical workflow of sample/simple_sample.py:58-91 with W kept on the device."""
+    g = load_golden("nino3_simple")
+    m = pycwt_amd.Morlet(6)
+    dt, dj = 0.25, 1 / 12
+    T = pycwt_amd.cwt_device(g["x"], dt, dj, 0.5, 84, m)
+    W = g["W"]
+    power = np.abs(W) ** 2
+    assert T.shape == W.shape
+    per_row, _ = row_errors(T.W(), W)
+    assert per_row.max() < 1e-12
+    np.testing.assert_allclose(T.global_power(), power.mean(axis=1), rtol=1e-11)
+    period = 1 / g["freqs"]
+    sel = (period >= 2) & (period < 8)                  # simple_sample.py:85-91
+    s1, s2 = g["sj"][sel].min(), np.nextafter(g["sj"][sel].max(), np.inf)
+    expect = dj * dt / m.cdelta * (power / g["sj"][:, None])[sel].sum(axis=0)
+    np.testing.assert_allclose(T.scale_average(s1, s2, dj), expect, rtol=1e-11)
+    np.testing.assert_allclose(T.icwt(dj), g["icwt"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(T.sj, g["sj"])
+    np.testing.assert_allclose(T.coi, g["coi"])
+    T.close()
