@@ -67,6 +67,7 @@ struct cwt_plan {
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
@@ -212,6 +213,8 @@ void profile_support(int mother, double p, double eps, double* f_lo, double* f_h
   }
 }
 
+int two_pass_logk(const cwt_plan* p);
+
 // Mother constant conj(c) with psi_ft(f) = c * profile(f)  (mothers.py:26-28, 118-122, 170-173)
 int mother_constant(int mother, double param, double* cre, double* cim) {
   const double pi = 3.14159265358979323846;
@@ -249,6 +252,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int logP = std::min(p->log_wg_points, p->logN);
   const bool use_small = p->logN <= p->loglmax;
   const int narrow_cap = std::min(p->narrow_max_logk, logP - 1);
+  // pass A specialised for narrow column supports exists for R = 1024 at the default geometry only
+  const bool band_pass_a = p->use_ct && p->band_pass_a && p->logN - two_pass_logk(p) == 10 &&
+                           logP == (p->prec == 64 ? 13 : 14);
   // the multi-term form exists only in the compile-time kernel for K = 1024 at the default geometry
   const bool multi_ok = p->use_ct && p->narrow_terms > 1 && narrow_cap >= 10 &&
                         logP == (p->prec == 64 ? 13 : 14);
@@ -287,6 +293,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         rd.nterms = (rd.nband + 1023) >> 10;
         narrow_rows.push_back(rd);
       } else {
+        // pass A class: how many bins k1 of a column can be non-zero (see pass_a_band_body)
+        const int span = (rd.nband >> two_pass_logk(p)) + 2;
+        rd.logK = !band_pass_a ? 0 : span <= 16 ? 4 : span <= 64 ? 6 : span <= 256 ? 8 : 0;
         wide_rows.push_back(rd);
       }
     }
@@ -368,6 +377,13 @@ template <typename T, int MODE>
 bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
                    long n0, long in_ld, cplx<T>* Z, hipStream_t st) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
+  if (MODE == IN_SPECTRUM && logR == 10) {          // per-row dispatch: full or band-limited column FFTs
+    constexpr int LOGP = default_logp<T>();
+    hipLaunchKernelGGL((k_pass_a_ct_rows<T, 10, LOGP>), dim3(1u << (p->logN - LOGP), cnt), dim3(1 << (LOGP - 4)),
+                       (size_t(1) << LOGP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
+                       static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+    return true;
+  }
   switch (logR) {
     case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
     case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
@@ -666,6 +682,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "profile") p->profile = value != 0;
   else if (k == "ct") p->use_ct = value != 0;
   else if (k == "overlap") p->overlap = value != 0;
+  else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");

@@ -566,6 +566,110 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
   }
 }
 
+// Pass A for a row whose support spans only c <= C = 2^LOGC of the R = 2^LOGR bins k1 of every column q
+// (k = q + K k1): the column transform has c consecutive non-zero inputs u_q[a] = Y[k_lo + d0(q) + K a],
+// so with r = R2 m' + r' (R2 = R / C) it is, for each r', a C-point FFT of the aliased twiddled inputs
+//   V[q'] = u_q[a(q')] e^{2 pi i (k1_base + a(q')) r' / R},  a(q') = (q' - k1_base) mod C,
+// exactly the band-limited form of k_narrow one level down.  8 columns x R2 residues per workgroup (the
+// same 8R points as the full pass A), log2 C instead of log2 R butterfly levels, and only 8 C filter
+// evaluations per workgroup.  Z layout and the trailing twiddle e^{2 pi i q r / N} are unchanged.
+template <typename T, int LOGR, int LOGP, int LOGC>
+__device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
+                                                 const Mother& mo, const cplx<T>* __restrict__ tw_all,
+                                                 const TwN<T>& twn, int logN, cplx<T>* __restrict__ z, T* lds) {
+  constexpr int LOGTQ = LOGP - LOGR, LOGR2 = LOGR - LOGC, LOGTB = LOGTQ + LOGR2;
+  constexpr int C = 1 << LOGC, LOGNT = LOGC - 4, NT = 1 << LOGNT, TQ = 1 << LOGTQ;
+  using F = ct::Fft<T, LOGC, LOGTB, true>;
+  const int N = 1 << logN, logK = logN - LOGR, K = 1 << logK;
+  const unsigned nm = unsigned(N - 1);
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTB) - 1);
+  f.j = threadIdx.x >> LOGTB;
+  const int tq = f.t & (TQ - 1);
+  const unsigned rp = unsigned(f.t) >> LOGTQ;                       // residue r' < R2
+  const int q0 = blockIdx.x << LOGTQ;
+
+  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);                 // [a][tq], a < C
+  for (int idx = threadIdx.x; idx < (C << LOGTQ); idx += (1 << (LOGP - 4))) {
+    const int d0 = (q0 + (idx & (TQ - 1)) - rd.k_lo) & (K - 1);
+    ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d0 + ((idx >> LOGTQ) << logK), N - 1);
+  }
+  __syncthreads();
+  const int q = q0 + tq;
+  const int kb = rd.k_lo + ((q - rd.k_lo) & (K - 1));               // signed bin of this column's first term
+  const int k1b = (kb - q) >> logK;                                 // its k1 (may be negative): exact division
+  T re[16], im[16];
+  {
+    int a = (f.j - k1b) & (C - 1);
+    cplx<T> cur = twn(((unsigned(k1b + a) * rp) << logK) & nm);     // e^{2 pi i (k1b + a) r' / R}
+    const cplx<T> step = twn(((unsigned(NT) * rp) << logK) & nm);
+    const cplx<T> stepw = cmul<T>(step, twn((0u - ((rp << LOGC) << logK)) & nm));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const cplx<T> y = ytile[(a << LOGTQ) + tq];
+      re[e] = y.x * cur.x - y.y * cur.y;
+      im[e] = y.x * cur.y + y.y * cur.x;
+      const int an = (a + NT) & (C - 1);
+      cur = cmul<T>(cur, an < a ? stepw : step);
+      a = an;
+    }
+  }
+  __syncthreads();                                                   // the tile aliases the exchange buffer
+  f.run(re, im, lds, tw_all + (C - 2));
+  // slot e holds m' = j + e*NT  ->  r = R2 m' + r'
+  const unsigned r0 = (unsigned(f.j) << LOGR2) + rp;
+  cplx<T> cur = twn(unsigned(q) * r0);
+  const cplx<T> step = twn((unsigned(q) << LOGNT) << LOGR2);
+  const unsigned off = (r0 << logK) + unsigned(q);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    (z + ((long(e * NT) << LOGR2) << logK))[off] =
+        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
+    cur = cmul<T>(cur, step);
+  }
+}
+
+// Pass A of a chunk of wide rows: every workgroup branches once on its row's class (rd.logK: 0 = all
+// R inputs may be non-zero -> full column FFT; 4/6/8 -> support spans <= 16/64/256 bins k1).
+template <typename T, int LOGR, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ Z) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+  cplx<T>* z = Z + (long(blockIdx.y) << logN);
+  if (rd.logK == 4) { pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  if (rd.logK == 6) { pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  if (rd.logK == 8) { pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  // full column FFT (same code as k_pass_a_ct<..., IN_SPECTRUM>)
+  constexpr int LOGTQ = LOGP - LOGR, LOGNT = LOGR - 4, NT = 1 << LOGNT;
+  using F = ct::Fft<T, LOGR, LOGTQ, true>;
+  const int N = 1 << logN, logK = logN - LOGR;
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTQ) - 1);
+  f.j = threadIdx.x >> LOGTQ;
+  const unsigned q = (blockIdx.x << LOGTQ) + f.t;
+  const unsigned k0 = q + (unsigned(f.j) << logK);
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = int(k0 + (unsigned(e * NT) << logK));
+    const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
+    re[e] = v.x; im[e] = v.y;
+  }
+  f.run(re, im, lds, tw_all + ((1 << LOGR) - 2));
+  const unsigned off = (unsigned(f.j) << logK) + q;
+  cplx<T> cur = twn(q * unsigned(f.j));
+  const cplx<T> step = twn(q << LOGNT);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    (z + (long(e * NT) << logK))[off] =
+        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
+    cur = cmul<T>(cur, step);
+  }
+}
+
 template <typename T, int LOGK, int LOGP, bool CONJ>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 4 : 8))
 k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,

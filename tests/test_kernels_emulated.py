@@ -128,3 +128,23 @@ def test_profile_timings_and_errors(emu_library):
     with pytest.raises(_hip.HipError, match="Paul"):
         plan.execute_host(x, orc.PAUL, 2.5, 1.0, [2.0])
     plan.close()
+
+
+@pytest.mark.parametrize("kind,param,scales", [(orc.MORLET, 6, [380.0, 76.0, 15.0, 3.0]),
+                                               (orc.DOG, 2, [600.0, 150.0, 30.0, 1.0]),
+                                               (orc.PAUL, 4, [200.0, 40.0, 10.0])])
+def test_pass_a_classes_at_full_size(emu_library, kind, param, scales):
+    """N = 2^20 (R = K = 1024): rows whose support spans <= 16 / 64 / 256 column bins use the aliased
+    short column FFTs of pass_a_band_body, wider ones the full column FFT; all through one launch."""
+    N = 1 << 20
+    x = np.random.default_rng(5).standard_normal(N - 3)
+    m = orc.Mother(kind, param)
+    sj = np.array(scales)
+    ref = orc.cwt_rows(x, 1.0, sj, m)[:, :x.size]
+    for opts in (None, {"band_pass_a": 0}):
+        plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options=opts)
+        W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+        assert plan.last_split()["two_pass"] == len(scales)
+        plan.close()
+        per_row, _ = row_errors(W, ref)
+        assert per_row.max() < 1e-12, (opts, per_row)
