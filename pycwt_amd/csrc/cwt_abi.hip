@@ -351,17 +351,21 @@ template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 
 
 // all band-limited rows in one launch (k_narrow_ct_all); false if the geometry is not the default one
 template <typename T>
-bool try_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
-                       int64_t ncols) {
-  constexpr int LOGP = default_logp<T>();
-  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != LOGP) return false;
+bool narrow_ct_all_applies(const cwt_plan* p) {
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
   for (const auto& g : p->narrow_groups)
     if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 4 || (g.nterms > 1 && g.logK != 10)) return false;
+  return true;
+}
+
+template <typename T>
+void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
+                          int64_t ncols) {
+  constexpr int LOGP = default_logp<T>();
   hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), p->n_narrow),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                      p->rows_dev + p->narrow_groups.front().first, mo, static_cast<const cplx<T>*>(p->tw_all),
                      twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
-  return true;
 }
 
 template <typename T, int LOGR, int MODE>
@@ -534,10 +538,10 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   }
   // band-limited rows go to the plan's own stream
   if (p->n_narrow) {
-    bool done = false;
-    rc = timed_launch(p, KC_NARROW, [&] { done = try_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
-    if (rc) return rc;
-    if (!done) {
+    if (narrow_ct_all_applies<T>(p)) {
+      rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      if (rc) return rc;
+    } else {
       for (const auto& g : p->narrow_groups) {
         rc = timed_launch(p, KC_NARROW, [&] {
           hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
