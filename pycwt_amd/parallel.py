@@ -133,7 +133,9 @@ def icwt_sharded(W_local, sj_local, dt, dj=1 / 12, wavelet="morlet", *, group=No
     part = torch.zeros(W_local.shape[1], dtype=real_t, device=W_local.device)
     if W_local.shape[0]:
         if engine is None:
-            raise ValueError("pass the engine used by cwt_sharded (it owns the device plan)")
+            n = W_local.shape[1]
+            engine = HipEngine(_next_pow2(max(n, 2)), 64 if real_t == torch.float64 else 32, W_local.shape[0],
+                               W_local.device.index or 0)
         engine.icwt_partial(W_local, np.ascontiguousarray(sj_local, dtype=np.float64), part)
     if world > 1:
         dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM, group=group)

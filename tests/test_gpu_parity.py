@@ -205,6 +205,8 @@ def test_sharded_api_single_rank_matches_cwt(hip_library):
     assert per_row.max() < 1e-12
     np.testing.assert_allclose(sj, ref[1])
     np.testing.assert_allclose(coi, ref[3])
+    iw = parallel.icwt_sharded(W, sj[mine], 0.5, 0.25, "dog")
+    np.testing.assert_allclose(iw, pycwt_amd.icwt(ref[0], ref[1], 0.5, 0.25, "dog"), rtol=1e-11, atol=1e-12)
 
 
 @pytest.mark.parametrize("logn,prec,rows", [(21, 64, 6), (22, 64, 5), (23, 32, 4), (24, 32, 3), (24, 64, 2)])
