@@ -358,14 +358,18 @@ bool narrow_ct_all_applies(const cwt_plan* p) {
   return true;
 }
 
+constexpr int kMaxGridY = 32768;   // rows per launch (gridDim.y is limited to 65535)
+
 template <typename T>
 void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
                           int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
-  hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), p->n_narrow),
-                     dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
-                     p->rows_dev + p->narrow_groups.front().first, mo, static_cast<const cplx<T>*>(p->tw_all),
-                     twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
+  const int first = p->narrow_groups.front().first;
+  for (int r0 = 0; r0 < p->n_narrow; r0 += kMaxGridY)
+    hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, p->n_narrow - r0)),
+                       dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
+                       p->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
+                       p->logN, W, long(ldw), long(ncols));
 }
 
 template <typename T, int LOGR, int MODE>
@@ -544,9 +548,11 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     } else {
       for (const auto& g : p->narrow_groups) {
         rc = timed_launch(p, KC_NARROW, [&] {
-          hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), g.count), dim3(threads), lds, p->stream,
-                             xhat, p->rows_dev + g.first, mo, tw_table<T>(p, g.logK), twn_of<T>(p), logN,
-                             g.logK, logP - g.logK, W, long(ldw), long(ncols));
+          for (int r0 = 0; r0 < g.count; r0 += kMaxGridY)
+            hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), std::min(kMaxGridY, g.count - r0)),
+                               dim3(threads), lds, p->stream, xhat, p->rows_dev + g.first + r0, mo,
+                               tw_table<T>(p, g.logK), twn_of<T>(p), logN, g.logK, logP - g.logK, W, long(ldw),
+                               long(ncols));
         });
         if (rc) return rc;
       }
