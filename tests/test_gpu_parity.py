@@ -354,3 +354,53 @@ def test_device_resident_workflow_on_gpu(hip_library):
                                rtol=1e-10)
     np.testing.assert_allclose(T.icwt(dj), orc.icwt(W, T.sj, 1.0, dj, "morlet"), rtol=1e-10, atol=1e-11)
     T.close()
+
+
+def test_config5_deterministic_part_at_full_size(hip_library):
+    """BASELINE config 5 without the Monte-Carlo loop: xwt and wct of two N = 2^20 series on the device
+    (per-row-spectrum smoothing through the band-limited and two-pass kernels).  Checked against NumPy on
+    sampled scales (the smoothing of mothers.py:61-104 restated with scipy.fft on those rows only)."""
+    import scipy.fft as sfft
+    from pycwt_amd.helpers import rect
+    n = 1 << 20
+    rng = np.random.default_rng(55)
+    e = rng.standard_normal(n)
+    y1 = e + np.sin(2 * np.pi * np.arange(n) / 500.0)
+    y2 = 0.5 * np.roll(e, 3) + rng.standard_normal(n) + np.sin(2 * np.pi * np.arange(n) / 500.0 + 0.7)
+    dt, dj = 1.0, 0.5
+    m = pycwt_amd.Morlet(6)
+    WCT, aWCT, coi, freq, sig = pycwt_amd.wct(y1, y2, dt, dj, sig=False)
+    rows = WCT.shape[0]
+    assert WCT.shape == (rows, n) and np.isfinite(WCT).all() and WCT.min() >= 0 and WCT.max() <= 1 + 1e-9
+    # reference for scale rows j0..j1 needs the boxcar neighbours: rebuild the unsmoothed inputs on a window of scales
+    sj = 1 / (m.flambda() * freq)
+    y1n, y2n = (y1 - y1.mean()) / y1.std(), (y2 - y2.mean()) / y2.std()
+    win = rect(int(np.round(m.deltaj0 / dj * 2)), normalize=True)
+    half = (len(win) - 1) // 2
+    for j in (3, 17, rows - 4):
+        lo, hi = max(0, j - half - 1), min(rows, j + half + 2)
+        o = orc.Mother(orc.MORLET, 6)
+        W1 = orc.cwt_rows(y1n, dt, sj[lo:hi], o)
+        W2 = orc.cwt_rows(y2n, dt, sj[lo:hi], o)
+        k2 = (2 * np.pi * np.fft.fftfreq(n)) ** 2
+        def tsmooth(T):
+            F = np.exp(-0.5 * (sj[lo:hi, None] / dt) ** 2 * k2)
+            return sfft.ifft(F * sfft.fft(T, axis=1), axis=1)
+        S1 = tsmooth(np.abs(W1) ** 2 / sj[lo:hi, None]).real
+        S2 = tsmooth(np.abs(W2) ** 2 / sj[lo:hi, None]).real
+        S12 = tsmooth(W1 * W2.conj() / sj[lo:hi, None])
+        def box(T, jj):                                   # convolve2d(T, win[:, None], 'same') at row jj
+            acc = 0
+            for i, w in enumerate(win):
+                r = jj + half - i
+                if 0 <= r < rows:
+                    acc = acc + w * T[r - lo]
+            return acc
+        ref = np.abs(box(S12, j)) ** 2 / (box(S1, j) * box(S2, j))
+        assert np.abs(WCT[j] - ref).max() < 1e-9, j
+        assert np.abs(np.angle(np.exp(1j * (aWCT[j] - np.angle(W1[j - lo] * W2[j - lo].conj()))))).max() < 1e-8
+    W12, xcoi, xfreq, xsig = pycwt_amd.xwt(y1, y2, dt, dj)
+    assert W12.shape == (rows, n)
+    o = orc.Mother(orc.MORLET, 6)
+    ref = orc.cwt_rows(y1n, dt, sj[[5]], o) * orc.cwt_rows(y2n, dt, sj[[5]], o).conj()
+    assert np.abs(W12[5] - ref[0]).max() < 1e-10 * np.abs(ref).max()
