@@ -738,13 +738,12 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
 }
 
 namespace {
-int run_filter_rows(cwt_plan* p, const void* spec_dev, int mother, double param, int nrows, void* W_dev,
-                    int64_t ldw, int64_t ncols) {
-  HIPCHECK(hipStreamSynchronize(p->stream));  // the pinned staging buffer may still be in flight
+// Copies the freshly built row table to the device through the pinned staging buffer.
+int upload_row_table(cwt_plan* p) {
+  HIPCHECK(hipStreamSynchronize(p->stream));  // the staging buffer of the previous call may still be in flight
   std::memcpy(p->rows_pinned, p->table.data(), p->table.size() * sizeof(RowDesc));
   HIPCHECK(hipMemcpyAsync(p->rows_dev, p->rows_pinned, p->table.size() * sizeof(RowDesc),
                           hipMemcpyHostToDevice, p->stream));
-  (void)nrows;
   return CWT_OK;
 }
 }  // namespace
@@ -774,7 +773,7 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
       ai[j] = norm * cim;
     }
     rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows);
-    if (!rc) rc = run_filter_rows(p, xhat_dev, mother, param, nrows, W_dev, ldw, ncols);
+    if (!rc) rc = upload_row_table(p);
     if (rc) return rc;
     p->last_mother = mother; p->last_param = param; p->last_dt = dt;
     p->last_scales.assign(scales, scales + nrows);
@@ -814,7 +813,7 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   }
   // W is treated as one (nbatch*nrows) x ldw matrix: row b*nrows + j = scale j of signal b
   rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), xhat_ld, total, nullptr, nullptr, nrows);
-  if (!rc) rc = run_filter_rows(p, xhat_dev, mother, param, total, W_dev, ldw, ncols);
+  if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
   p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
   Mother mo;
@@ -832,7 +831,7 @@ int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* tabl
   p->table_valid = false;
   std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
   int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
-  if (!rc) rc = run_filter_rows(p, xhat_dev, MOTHER_TABLE, 0.0, nrows, W_dev, ldw, ncols);
+  if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
   p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
   Mother mo;
@@ -866,7 +865,7 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   double cre, cim;
   int rc = mother_constant(mother, param, &cre, &cim);   // validates mother / order only
   if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
-  if (!rc) rc = run_filter_rows(p, spec_dev, mother, param, nrows, W_dev, ldw, ncols);
+  if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
   p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
   Mother mo;
