@@ -153,6 +153,7 @@ def main():
     # ---- per-kernel HIP-event timing (separate passes so the events do not perturb `value`) ----
     plan.set_option("profile", 1)
     plan.set_option("overlap", 0)     # kernels one at a time, so that each duration is its own
+    plan.set_option("overlap_narrow", 0)
     prof_steps = max(3, min(10, args.steps))
     step(); fence(); plan.timings()
     for _ in range(prof_steps):
@@ -160,7 +161,8 @@ def main():
     fence()
     tm = plan.timings()
     plan.set_option("profile", 0)
-    plan.set_option("overlap", opts.get("overlap", 1))
+    plan.set_option("overlap", opts.get("overlap", 0))
+    plan.set_option("overlap_narrow", opts.get("overlap_narrow", 1 if prec == 64 else 0))
     split = plan.last_split()
     units_by_class = {"small": split["small"] * N, "narrow": split["narrow"] * N,
                       "pass_a": split["two_pass"] * N, "pass_b": split["two_pass"] * N}

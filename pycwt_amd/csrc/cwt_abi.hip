@@ -67,6 +67,7 @@ struct cwt_plan {
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   // device resources
@@ -500,6 +501,10 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int logP = std::min(p->log_wg_points, logN);
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
+  if (p->overlap_narrow && !p->overlap && p->n_wide && p->n_narrow) {   // side stream 0 starts after the spectrum exists
+    HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
+    HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
+  }
   if (p->n_wide) {
     const int logK = two_pass_logk(p), logR = logN - logK;
     const int chunk = std::max(1, std::min(chunk_rows_of(p), p->n_wide));
@@ -540,11 +545,18 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
   }
-  // band-limited rows go to the plan's own stream
+  // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
+  // tails) when "overlap_narrow" is set, else on the plan's own stream
+  bool narrow_on_side = false;
   if (p->n_narrow) {
     if (narrow_ct_all_applies<T>(p)) {
+      hipStream_t keep = p->stream;
+      narrow_on_side = p->overlap_narrow && p->n_wide && !(p->overlap);
+      if (narrow_on_side) p->stream = p->side[0];
       rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      p->stream = keep;
       if (rc) return rc;
+      if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
     } else {
       for (const auto& g : p->narrow_groups) {
         rc = timed_launch(p, KC_NARROW, [&] {
@@ -566,6 +578,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
     }
   }
+  if (narrow_on_side) HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_a[0], 0));
   return CWT_OK;
 }
 
@@ -631,6 +644,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->prec = precision;
   p->max_rows = max_rows;
   p->log_wg_points = precision == 64 ? 13 : 14;
+  p->overlap_narrow = precision == 64;   // measured: +2 % in fp64, -3 % in fp32
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
@@ -693,6 +707,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ct") p->use_ct = value != 0;
   else if (k == "overlap") p->overlap = value != 0;
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
+  else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
