@@ -63,6 +63,13 @@ __global__ void k_seg_wave_sync(double2* W, int logN, int logK, double v) {
   for (int m = l; m < K; m += 64) { row[(size_t(m) << logR) + r] = make_double2(v + m, v - w); __syncthreads(); }
 }
 
+// copy with non-temporal stores (the pass-B pattern: read the just-written intermediate, stream W out)
+__global__ void k_copy_nt(const double2* __restrict__ a, double2* __restrict__ b, size_t n) {
+  typedef double v2 __attribute__((vector_size(16)));
+  size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) { double2 v = a[i]; v2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<v2*>(b) + i); }
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main() {
@@ -117,6 +124,19 @@ int main() {
     }
     printf("  %5zu MiB  write %8.1f GB/s   read-after-write %8.1f GB/s\n", mib, mib * 1.048576 / bestw,
            mib * 1.048576 / best);
+  }
+  printf("fill S MiB (plain stores), then copy it with nt stores to a disjoint 1 GiB area (time of the copy):\n");
+  for (size_t mib : {32, 64, 128, 192, 256, 512, 1024}) {
+    const size_t cnt = mib * 1024 * 1024 / 16;
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+      hipLaunchKernelGGL(k_fill, dim3(unsigned(cnt / 256)), dim3(256), 0, 0, A, cnt, double(rep));
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_copy_nt, dim3(unsigned(cnt / 256)), dim3(256), 0, 0, A, B, cnt);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      best = fminf(best, time_ms(e0, e1));
+    }
+    printf("  %5zu MiB  read+write %8.1f GB/s combined\n", mib, 2 * mib * 1.048576 / best);
   }
   return 0;
 }
