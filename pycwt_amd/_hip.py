@@ -125,9 +125,12 @@ class Plan:
             self.set_option(k, v)
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.cwt_plan_destroy(self.h)
-            self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.cwt_plan_destroy(h)
+            except Exception:       # interpreter shutdown: the library may already be gone
+                pass
 
     __del__ = close
 
@@ -241,9 +244,12 @@ class DeviceBuffer:
         self.ptr = p.value
 
     def free(self):
-        if getattr(self, "ptr", None):
-            self.lib.cwt_free(self.device, _P(self.ptr))
-            self.ptr = None
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                self.lib.cwt_free(self.device, _P(ptr))
+            except Exception:       # interpreter shutdown
+                pass
 
     __del__ = free
 
