@@ -253,9 +253,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int logP = std::min(p->log_wg_points, p->logN);
   const bool use_small = p->logN <= p->loglmax;
   const int narrow_cap = std::min(p->narrow_max_logk, logP - 1);
-  // pass A specialised for narrow column supports exists for R = 1024 at the default geometry only
-  const bool band_pass_a = p->use_ct && p->band_pass_a && p->logN - two_pass_logk(p) == 10 &&
-                           logP == (p->prec == 64 ? 13 : 14);
+  // pass A specialised for narrow column supports (default geometry only)
+  const int two_pass_logr = p->logN - two_pass_logk(p);
+  const bool band_pass_a = p->use_ct && p->band_pass_a && logP == (p->prec == 64 ? 13 : 14);
   // the multi-term form exists only in the compile-time kernel for K = 1024 at the default geometry
   const bool multi_ok = p->use_ct && p->narrow_terms > 1 && narrow_cap >= 10 &&
                         logP == (p->prec == 64 ? 13 : 14);
@@ -296,7 +296,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       } else {
         // pass A class: how many bins k1 of a column can be non-zero (see pass_a_band_body)
         const int span = (rd.nband >> two_pass_logk(p)) + 2;
-        rd.logK = !band_pass_a ? 0 : span <= 16 ? 4 : span <= 64 ? 6 : span <= 256 ? 8 : 0;
+        const int cls = span <= 16 ? 4 : span <= 64 ? 6 : span <= 256 ? 8 : 0;
+        rd.logK = (band_pass_a && cls && cls < two_pass_logr) ? cls : 0;   // only if shorter than the column
         wide_rows.push_back(rd);
       }
     }
@@ -330,8 +331,12 @@ int chunk_rows_of(const cwt_plan* p) {
   return int(std::max<size_t>(1, (size_t(192) << 20) / row_bytes));
 }
 
+// N = R*K.  K = 1024 up to N = 2^21, K = 2048 at 2^22 and 2^23 (measured: 155 vs 117 GS/s at 2^22 against
+// K = 1024, 106 vs 60 at 2^23 against K = 4096: 32-byte store tiles in pass B hurt more than in pass A),
+// K = 4096 at 2^24 (forced by the 4096-point workgroup FFT limit).
 int two_pass_logk(const cwt_plan* p) {
   int lk = std::min(10, p->logN - 4);
+  if (p->logN >= 22) lk = 11;
   lk = std::max(lk, p->logN - p->loglmax);
   lk = std::min(lk, p->loglmax);
   return lk;
@@ -382,36 +387,54 @@ void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt,
                      tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
 }
 
+template <typename T, int LOGR>
+void launch_pass_a_ct_rows(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
+                           cplx<T>* Z, hipStream_t st) {
+  constexpr int LOGP = default_logp<T>();
+  hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LOGP>), dim3(1u << (p->logN - LOGP), cnt), dim3(1 << (LOGP - 4)),
+                     (size_t(1) << LOGP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
+                     static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+}
+
+// Compile-time pass A for every column length R = 2^4 .. 2^12 (i.e. every N the two-pass path handles).
 template <typename T, int MODE>
 bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
                    long n0, long in_ld, cplx<T>* Z, hipStream_t st) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  if (MODE == IN_SPECTRUM && logR == 10) {          // per-row dispatch: full or band-limited column FFTs
-    constexpr int LOGP = default_logp<T>();
-    hipLaunchKernelGGL((k_pass_a_ct_rows<T, 10, LOGP>), dim3(1u << (p->logN - LOGP), cnt), dim3(1 << (LOGP - 4)),
-                       (size_t(1) << LOGP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
-                       static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+#define CWT_CASE(LR)                                                                                  \
+  case LR:                                                                                            \
+    if constexpr (MODE == IN_SPECTRUM) launch_pass_a_ct_rows<T, LR>(p, in, rows, cnt, mo, Z, st);    \
+    else launch_pass_a_ct<T, LR, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st);                       \
     return true;
-  }
   switch (logR) {
-    case 4: launch_pass_a_ct<T, 4, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
-    case 6: launch_pass_a_ct<T, 6, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
-    case 8: launch_pass_a_ct<T, 8, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
-    case 10: launch_pass_a_ct<T, 10, MODE>(p, in, rows, cnt, mo, n0, in_ld, Z, st); return true;
+    CWT_CASE(4) CWT_CASE(5) CWT_CASE(6) CWT_CASE(7) CWT_CASE(8) CWT_CASE(9) CWT_CASE(10) CWT_CASE(11) CWT_CASE(12)
     default: return false;
   }
+#undef CWT_CASE
 }
 
+template <typename T, int LOGK, bool CONJ>
+void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
+                      const cplx<T>* Z, hipStream_t st) {
+  constexpr int LOGP = default_logp<T>();
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LOGP, CONJ>), dim3(1u << (p->logN - LOGP), cnt),
+                     dim3(1 << (LOGP - 4)), lds, st, Z, rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw),
+                     long(ncols));
+}
+
+// Compile-time pass B for row lengths K = 2^9 .. 2^12 (K = 1024 for every N from 2^14 to 2^22).
 template <typename T, bool CONJ>
 bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw,
                    int64_t ncols, const cplx<T>* Z, hipStream_t st) {
-  constexpr int LOGP = default_logp<T>();
-  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != LOGP || logK != 10) return false;
-  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-  hipLaunchKernelGGL((k_pass_b_ct<T, 10, LOGP, CONJ>), dim3(1u << (p->logN - LOGP), cnt),
-                     dim3(1 << (LOGP - 4)), lds, st, Z, rows, tw_table<T>(p, 10), p->logN, W, long(ldw),
-                     long(ncols));
-  return true;
+  if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
+  switch (logK) {
+    case 9: launch_pass_b_ct<T, 9, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st); return true;
+    case 10: launch_pass_b_ct<T, 10, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st); return true;
+    case 11: launch_pass_b_ct<T, 11, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st); return true;
+    case 12: launch_pass_b_ct<T, 12, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st); return true;
+    default: return false;
+  }
 }
 
 // Forward FFT of nrows rows (real, or complex for MODE = IN_CPLX), each zero padded from n0 to N:

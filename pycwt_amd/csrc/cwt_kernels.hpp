@@ -639,9 +639,12 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
   T* lds = reinterpret_cast<T*>(lds_raw);
   const RowDesc rd = rows[blockIdx.y];
   cplx<T>* z = Z + (long(blockIdx.y) << logN);
-  if (rd.logK == 4) { pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
-  if (rd.logK == 6) { pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
-  if (rd.logK == 8) { pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  if constexpr (LOGR > 4)
+    if (rd.logK == 4) { pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  if constexpr (LOGR > 6)
+    if (rd.logK == 6) { pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+  if constexpr (LOGR > 8)
+    if (rd.logK == 8) { pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
   // full column FFT (same code as k_pass_a_ct<..., IN_SPECTRUM>)
   constexpr int LOGTQ = LOGP - LOGR, LOGNT = LOGR - 4, NT = 1 << LOGNT;
   using F = ct::Fft<T, LOGR, LOGTQ, true>;

@@ -148,3 +148,10 @@ def test_pass_a_classes_at_full_size(emu_library, kind, param, scales):
         plan.close()
         per_row, _ = row_errors(W, ref)
         assert per_row.max() < 1e-12, (opts, per_row)
+
+
+@pytest.mark.parametrize("logn", [15, 17, 19])
+def test_odd_column_lengths_default_geometry(emu_library, logn):
+    """N = 2^15, 2^17, 2^19 -> column FFTs of 32, 128, 512 points (compile-time kernels for every R)."""
+    split = run_case(emu_library, 1 << logn, (1 << logn) - 9, orc.MORLET, 6, 6 if logn < 19 else 4)
+    assert split["two_pass"] > 0
