@@ -215,6 +215,7 @@ void profile_support(int mother, double p, double eps, double* f_lo, double* f_h
 }
 
 int two_pass_logk(const cwt_plan* p);
+int check_geometry(const cwt_plan* p);
 
 // Mother constant conj(c) with psi_ft(f) = c * profile(f)  (mothers.py:26-28, 118-122, 170-173)
 int mother_constant(int mother, double param, double* cre, double* cim) {
@@ -340,6 +341,17 @@ int two_pass_logk(const cwt_plan* p) {
   lk = std::max(lk, p->logN - p->loglmax);
   lk = std::min(lk, p->loglmax);
   return lk;
+}
+
+// The tuning options can describe geometries the kernels do not support (they exist for tests); refuse them.
+int check_geometry(const cwt_plan* p) {
+  if (p->logN <= p->loglmax) return CWT_OK;                     // single-workgroup transform: nothing to check
+  if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
+  const int logK = two_pass_logk(p), logR = p->logN - logK, logP = std::min(p->log_wg_points, p->logN);
+  if (logK < 4 || logR < 4) return fail(CWT_EINVAL, "two-pass transform needs both factors >= 16: raise lmax");
+  if (logP < logK || logP < logR)
+    return fail(CWT_EINVAL, "wg_points must be at least as large as both two-pass factors");
+  return CWT_OK;
 }
 
 int ensure_z(cwt_plan* p, int rows) {
@@ -721,6 +733,11 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
   p->table_valid = false;
+  const int old_lmax = p->loglmax, old_wg = p->log_wg_points;
+  struct Restore {   // a rejected geometry leaves the plan as it was
+    cwt_plan* p; int lmax, wg; bool armed = true;
+    ~Restore() { if (armed && check_geometry(p) != CWT_OK) { p->loglmax = lmax; p->log_wg_points = wg; } }
+  } restore{p, old_lmax, old_wg};
   if (k == "chunk_rows") { if (value < 0) return fail(CWT_EINVAL, "chunk_rows >= 0"); p->chunk_rows = int(value); }
   else if (k == "narrow") p->narrow = value != 0;
   else if (k == "narrow_max_k") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "narrow_max_k: power of two in [16,4096]"); p->narrow_max_logk = ilog2(value); }
@@ -733,8 +750,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
-  if (p->logN > 2 * p->loglmax) return fail(CWT_EINVAL, "nfft exceeds lmax^2 (two-pass limit)");
-  return CWT_OK;
+  return check_geometry(p);
 }
 
 int cwt_plan_sync(cwt_plan* p) {

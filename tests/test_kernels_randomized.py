@@ -1,0 +1,70 @@
+"""Randomised geometry sweep of the kernel sources on the CPU emulation (hypothesis): transform length,
+ragged signal length, mother, scale set (unsorted, repeated, extreme), precision and the plan's geometry
+overrides are drawn at random and the result is compared with the oracle.  Complements the hand-picked
+cases of test_kernels_emulated.py."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from conftest import row_errors
+from oracle import cwt_oracle as orc
+from pycwt_amd import _hip
+
+MOTHERS = [(orc.MORLET, 6), (orc.MORLET, 3.5), (orc.PAUL, 4), (orc.PAUL, 1), (orc.DOG, 2), (orc.DOG, 5), (orc.DOG, 0)]
+
+
+@st.composite
+def cases(draw):
+    logn = draw(st.integers(2, 15))
+    N = 1 << logn
+    n0 = draw(st.integers(N // 2 + 1, N))
+    kind, param = draw(st.sampled_from(MOTHERS))
+    nrows = draw(st.integers(1, 9))
+    # scales from far below the resolvable range to far above the series length
+    expo = draw(st.lists(st.floats(-2.0, float(logn) + 2.0), min_size=nrows, max_size=nrows))
+    prec = draw(st.sampled_from([64, 64, 32]))
+    opts = {}
+    if logn >= 6 and draw(st.booleans()):
+        lmax = 1 << draw(st.integers(max(4, (logn + 1) // 2), min(12, logn)))
+        opts["lmax"] = lmax
+        if lmax < N:
+            opts["wg_points"] = 1 << draw(st.integers(8, 13))
+            opts["narrow"] = draw(st.integers(0, 1))
+            opts["chunk_rows"] = draw(st.integers(0, 3))
+            if draw(st.booleans()):
+                opts["narrow_max_k"] = 1 << draw(st.integers(4, 9))
+    if draw(st.booleans()):
+        opts["ct"] = draw(st.integers(0, 1))
+        opts["narrow_terms"] = draw(st.integers(1, 4))
+        opts["band_pass_a"] = draw(st.integers(0, 1))
+    return N, n0, kind, param, np.array([2.0 ** e for e in expo]), prec, opts, draw(st.integers(0, 2 ** 31))
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
+@given(cases())
+def test_random_geometry_matches_oracle(emu_library, case):
+    N, n0, kind, param, sj, prec, opts, seed = case
+    m = orc.Mother(kind, param)
+    sj = sj[~orc.dropped_rows(sj, 0.7, m)]
+    if sj.size == 0:
+        return
+    x = np.random.default_rng(seed).standard_normal(n0)
+    try:
+        plan = _hip.Plan(N, prec, max_rows=16, lib=emu_library, options=opts)
+    except _hip.HipError as e:           # option combinations the plan rejects by contract
+        assert "lmax" in str(e) or "nfft" in str(e) or "wg_points" in str(e)
+        return
+    W, xhat = plan.execute_host(x, kind, param, 0.7, sj)
+    plan.close()
+    ref = orc.cwt_rows(x, 0.7, sj, m, N=N)[:, :n0]
+    tol = 1e-11 if prec == 64 else 5e-5
+    xref = np.fft.fft(x, n=N)
+    assert np.abs(xhat - xref).max() <= tol * max(np.abs(xref).max(), 1e-300)
+    scale = np.abs(ref).max(axis=1)
+    err = np.abs(W - ref).max(axis=1)
+    # The engine treats bins whose filter profile is below 1e-18 (fp64) / 1e-9 (fp32) of the PROFILE'S PEAK as
+    # zero.  A scale whose support falls between the bins of a short series therefore comes out as exactly 0
+    # where the reference returns ~1e-60: allow an absolute error of that order relative to what a resolved
+    # row of this signal would carry (|W| <= sqrt(2 pi s/dt) * max|psi_ft| * ||x||_1 / ... ).
+    floor = (1e-15 if prec == 64 else 1e-7) * np.sqrt(2 * np.pi * sj / 0.7) * np.abs(x).sum()
+    assert (err <= tol * scale + floor).all(), (opts, err, scale)
