@@ -1,6 +1,6 @@
 # device-resident timing: batch of signals N=2^16, 128 rows, one launch set vs per-signal loop
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pycwt_amd import _hip
 nb, N, rows = 64, 1 << 16, 128

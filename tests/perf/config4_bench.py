@@ -1,8 +1,8 @@
 """BASELINE config 4 on ONE GPU: 1024 signals x N = 2^16, Morlet, 128 scales, device resident, processed in
 slabs of 128 signals (17 GB of W per slab, the slab buffer is re-used).  Prints throughput and checks
-sampled rows against the oracle.  python tools/config4_bench.py"""
+sampled rows against the oracle.  python tests/perf/config4_bench.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pycwt_amd import _hip
 from oracle import cwt_oracle as orc

@@ -1,7 +1,7 @@
 """Host-visible latency of the drop-in call pycwt_amd.cwt() (NumPy in, NumPy out, PCIe included) next to
-the CPU oracle, for short and medium series.  python tools/latency_bench.py"""
+the CPU oracle, for short and medium series.  python tests/perf/latency_bench.py"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pycwt_amd
 from oracle import cwt_oracle as orc
