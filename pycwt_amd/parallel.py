@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _hip
-from .wavelet import _check_parameter_wavelet, _device_id, _nan_rows, _next_pow2
+from .wavelet import _check_parameter_wavelet, _coi, _device_id, _nan_rows, _next_pow2, _scale_grid
 
 
 def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
@@ -89,21 +89,12 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
         dist.broadcast(x, src=src, group=group)            # the one exchange of the path
 
     # host scalars exactly as wavelet.py:75-88 / :111-115 / :120-121
-    if freqs is None:
-        if s0 == -1:
-            s0 = 2 * dt / mother.flambda()
-        if J == -1:
-            J = int(np.round(np.log2(n0 * dt / s0) / dj))
-        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-        freqs = 1 / (mother.flambda() * sj)
-    else:
-        sj = 1 / (mother.flambda() * freqs)
-    sj = np.asarray(sj, dtype=np.float64)
+    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
     N = _next_pow2(n0)
     bad = _nan_rows(mother, sj, N, dt)
     if bad.any() and not bad.all():
         sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
-    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    coi = _coi(mother, n0, dt)
 
     mine = shard_rows(sj.size, world, rank)
     kind, param = _device_id(mother)

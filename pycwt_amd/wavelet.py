@@ -59,6 +59,27 @@ def _next_pow2(n0: int) -> int:
     return int(2 ** np.ceil(np.log2(n0)))       # helpers.py:27-30
 
 
+def _scale_grid(mother, n0, dt, dj, s0, J, freqs):
+    """Scales and Fourier-equivalent frequencies exactly as wavelet.py:75-88: default s0 = 2*dt/flambda,
+    default J = round(log2(n0*dt/s0)/dj), sj = s0*2^(j*dj) for j = 0..J (J + 1 rows); or, when `freqs` is
+    given, sj = 1/(flambda*freqs)."""
+    if freqs is None:
+        if s0 == -1:
+            s0 = 2 * dt / mother.flambda()
+        if J == -1:
+            J = int(np.round(np.log2(n0 * dt / s0) / dj))
+        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+        freqs = 1 / (mother.flambda() * sj)
+    else:
+        sj = 1 / (mother.flambda() * freqs)
+    return np.asarray(sj, dtype=np.float64), freqs
+
+
+def _coi(mother, n0, dt):
+    """Cone of influence in Fourier periods (wavelet.py:120-121)."""
+    return mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+
+
 def _nan_rows(mother, sj, N, dt):
     """Rows the reference deletes at wavelet.py:111-115, decided without building W.
 
@@ -119,16 +140,7 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     n0 = len(signal)
-    if freqs is None:                                   # wavelet.py:75-85
-        if s0 == -1:
-            s0 = 2 * dt / mother.flambda()
-        if J == -1:
-            J = int(np.round(np.log2(n0 * dt / s0) / dj))
-        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-        freqs = 1 / (mother.flambda() * sj)
-    else:                                               # wavelet.py:86-88
-        sj = 1 / (mother.flambda() * freqs)
-    sj = np.asarray(sj, dtype=np.float64)
+    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
 
     N = _next_pow2(n0)
     real = np.float64 if precision == 64 else np.float32
@@ -151,8 +163,7 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
         W = W.astype(np.complex128)
         xhat = xhat.astype(np.complex128)
 
-    coi = n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2)      # wavelet.py:120-121
-    coi = mother.flambda() * mother.coi() * dt * coi
+    coi = _coi(mother, n0, dt)
     ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)                 # wavelet.py:94
     return (W, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
 
@@ -217,16 +228,7 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     n0 = len(signal)
-    if freqs is None:
-        if s0 == -1:
-            s0 = 2 * dt / mother.flambda()
-        if J == -1:
-            J = int(np.round(np.log2(n0 * dt / s0) / dj))
-        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-        freqs = 1 / (mother.flambda() * sj)
-    else:
-        sj = 1 / (mother.flambda() * freqs)
-    sj = np.asarray(sj, dtype=np.float64)
+    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
     N = _next_pow2(n0)
     bad = _nan_rows(mother, sj, N, dt)
     if bad.any() and not bad.all():
@@ -247,7 +249,7 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     finally:
         xd.free()
         xh.free()
-    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    coi = _coi(mother, n0, dt)
     ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
     return DeviceTransform(plan, Wd, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi),
                            mother, dt, n0)
@@ -266,16 +268,7 @@ def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     precision = _default_precision() if precision is None else int(precision)
     X = np.atleast_2d(np.asarray(signals))
     nb, n0 = X.shape
-    if freqs is None:
-        if s0 == -1:
-            s0 = 2 * dt / mother.flambda()
-        if J == -1:
-            J = int(np.round(np.log2(n0 * dt / s0) / dj))
-        sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-        freqs = 1 / (mother.flambda() * sj)
-    else:
-        sj = 1 / (mother.flambda() * freqs)
-    sj = np.asarray(sj, dtype=np.float64)
+    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
     N = _next_pow2(n0)
     bad = _nan_rows(mother, sj, N, dt)
     if bad.any() and not bad.all():
@@ -300,7 +293,7 @@ def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
             xhat[b0:b0 + cnt] = xh.download(plan, (cnt, N), plan.cplx)
     finally:
         sc.free()
-    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    coi = _coi(mother, n0, dt)
     ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
     return (W, sj, freqs, coi, xhat[:, 1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
 
@@ -498,7 +491,7 @@ def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, w
     sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
     freq = 1 / (mother.flambda() * sj)
     n0 = y1.size
-    coi = mother.flambda() * mother.coi() * dt * (n0 / 2 - np.abs(np.arange(0, n0) - (n0 - 1) / 2))
+    coi = _coi(mother, n0, dt)
     WCT, aWCT = _coherence_on_device(_normalised(y1, normalize), _normalised(y2, normalize), dt, dj, sj,
                                      mother, precision, device)
     if sig:
