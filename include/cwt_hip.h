@@ -72,6 +72,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "narrow_terms" largest number of aliased bins per FFT input of that path (1 = off)
  *   "overlap"      1 = run pass A of chunk c+1 beside pass B of chunk c on side
  *                  streams; 0 (default) = strictly one after the other
+ *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
  *   "overlap_narrow" 1 = queue the band-limited rows on a side stream beside the two-pass chain
  *                  (default for fp64), 0 = everything on the plan's stream
  *   "band_pass_a"  0 = always run the full column FFT in pass A (no short aliased column FFTs)

@@ -67,6 +67,7 @@ struct cwt_plan {
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
   int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
@@ -260,6 +261,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // the multi-term form exists only in the compile-time kernel for K = 1024 at the default geometry
   const bool multi_ok = p->use_ct && p->narrow_terms > 1 && narrow_cap >= 10 &&
                         logP == (p->prec == 64 ? 13 : 14);
+  // K = 2048 single-pass rows: fp64 only, N >= 2^14 (a 16384-point workgroup tile must fit the row)
+  const bool big_ok = p->use_ct && p->narrow_big && p->prec == 64 && narrow_cap >= 10 && logP == 13 &&
+                      p->logN >= 14;
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
   for (int j = 0; j < nrows; ++j) {
     if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
@@ -290,6 +294,11 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
+      } else if (p->narrow && big_ok && rd.nband <= (p->narrow_terms << 11) &&
+                 (rd.nband <= 2048 || rd.nband > (p->narrow_terms << 10))) {
+        rd.logK = 11;                                   // K = 2048, 16384-point workgroups (k_narrow_ct_big)
+        rd.nterms = (rd.nband + 2047) >> 11;
+        narrow_rows.push_back(rd);
       } else if (p->narrow && multi_ok && rd.nband <= (p->narrow_terms << 10)) {
         rd.logK = 10;                                   // several aliased bins per input (k_narrow_ct)
         rd.nterms = (rd.nband + 1023) >> 10;
@@ -303,7 +312,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       }
     }
   }
-  auto group_key = [](const RowDesc& x) { return x.logK + 100 * x.nterms; };
+  auto group_key = [](const RowDesc& x) { return (x.logK == 11 ? 1000 : 0) + x.logK + 100 * x.nterms; };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
   p->table.clear();
@@ -371,8 +380,10 @@ template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 
 template <typename T>
 bool narrow_ct_all_applies(const cwt_plan* p) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  for (const auto& g : p->narrow_groups)
+  for (const auto& g : p->narrow_groups) {
+    if (g.logK == 11 && sizeof(T) == 8 && g.nterms >= 1 && g.nterms <= 4) continue;      // k_narrow_ct_big
     if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 4 || (g.nterms > 1 && g.logK != 10)) return false;
+  }
   return true;
 }
 
@@ -382,12 +393,21 @@ template <typename T>
 void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
                           int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
+  // the row table is sorted by class: groups with K <= 1024 first, then (fp64) the K = 2048 groups
   const int first = p->narrow_groups.front().first;
-  for (int r0 = 0; r0 < p->n_narrow; r0 += kMaxGridY)
-    hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, p->n_narrow - r0)),
+  int n_small_k = 0, n_big = 0;
+  for (const auto& g : p->narrow_groups) (g.logK == 11 ? n_big : n_small_k) += g.count;
+  for (int r0 = 0; r0 < n_small_k; r0 += kMaxGridY)
+    hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_small_k - r0)),
                        dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                        p->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
                        p->logN, W, long(ldw), long(ncols));
+  if constexpr (sizeof(T) == 8) {
+    for (int r0 = 0; r0 < n_big; r0 += kMaxGridY)
+      hipLaunchKernelGGL((k_narrow_ct_big<T>), dim3(1u << (p->logN - 14), std::min(kMaxGridY, n_big - r0)), dim3(1024),
+                         (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rows_dev + first + n_small_k + r0, mo,
+                         static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
+  }
 }
 
 template <typename T, int LOGR, int MODE>
@@ -634,6 +654,9 @@ int set_func_attrs() {
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
       (void)hipGetLastError();
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_narrow_ct_big<double>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+    (void)hipGetLastError();
   return CWT_OK;
 }
 
@@ -748,6 +771,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "overlap") p->overlap = value != 0;
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
+  else if (k == "narrow_big") p->narrow_big = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);

@@ -511,6 +511,27 @@ k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 #undef CWT_NARROW_CASE
 }
 
+// fp64 only: rows whose support needs K = 2048 (or 2..4 aliased terms of 2048 bins, support <= 8192) run with
+// 16384 points per workgroup (1024 threads, 128 KiB of LDS, one workgroup per CU) so that the stores stay
+// 128-byte segments (TB = 8).  Converts rows of support 4096..8192 from the two-pass transform (48 B per
+// sample*scale of traffic) to the single-pass form (16 B).
+template <typename T>
+__global__ void __launch_bounds__(1024, 4)
+k_narrow_ct_big(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+                const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
+                long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+  switch (rd.nterms) {
+    case 1: narrow_ct_body<T, 11, 14, 1>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 2: narrow_ct_body<T, 11, 14, 2>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 3: narrow_ct_body<T, 11, 14, 3>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 4: narrow_ct_body<T, 11, 14, 4>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    default: break;
+  }
+}
+
 template <typename T, int LOGR, int LOGP, int MODE>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,

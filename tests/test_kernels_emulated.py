@@ -155,3 +155,25 @@ def test_odd_column_lengths_default_geometry(emu_library, logn):
     """N = 2^15, 2^17, 2^19 -> column FFTs of 32, 128, 512 points (compile-time kernels for every R)."""
     split = run_case(emu_library, 1 << logn, (1 << logn) - 9, orc.MORLET, 6, 6 if logn < 19 else 4)
     assert split["two_pass"] > 0
+
+
+@pytest.mark.parametrize("kind,param", [(orc.MORLET, 6), (orc.DOG, 2)])
+def test_k2048_single_pass_rows(emu_library, kind, param):
+    """fp64: supports of 1025..2048 bins (one term) and 4097..8192 bins (3-4 terms of 2048) run in the
+    16384-point-workgroup kernel instead of the two-pass transform."""
+    N = 1 << 16
+    x = np.random.default_rng(3).standard_normal(N)
+    m = orc.Mother(kind, param)
+    # support in bins ~ c*N/s with c = 2.9 (Morlet) / 2.5 (DOG m=2): aim at 1500, 3000, 6000, 8000, 12000 bins
+    c = 2.9 if kind == orc.MORLET else 2.5
+    sj = c * N / np.array([1500.0, 3000.0, 6000.0, 7900.0, 12000.0])
+    ref = orc.cwt_rows(x, 1.0, sj, m)
+    splits = {}
+    for big in (1, 0):
+        plan = _hip.Plan(N, 64, max_rows=8, lib=emu_library, options={"narrow_big": big})
+        W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+        splits[big] = plan.last_split()
+        plan.close()
+        per_row, _ = row_errors(W, ref)
+        assert per_row.max() < 1e-12, (big, per_row)
+    assert splits[1]["narrow"] > splits[0]["narrow"]
