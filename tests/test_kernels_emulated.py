@@ -78,8 +78,8 @@ def test_default_geometry_two_pass_8192(emu_library):
 @pytest.mark.parametrize("kind,param", [(orc.MORLET, 6), (orc.PAUL, 4), (orc.DOG, 2)])
 def test_band_limited_rows_with_several_aliased_terms(emu_library, terms, kind, param):
     """Supports wider than K = 1024 bins handled in one pass (compile-time kernels, default geometry)."""
-    one = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": 1})
-    many = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": terms})
+    one = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": 1, "narrow_big": 0})
+    many = run_case(emu_library, 16384, 16001, kind, param, 14, opts={"narrow_terms": terms, "narrow_big": 0})
     assert many["narrow"] > one["narrow"]
 
 
