@@ -141,7 +141,7 @@ def test_pass_a_classes_at_full_size(emu_library, kind, param, scales):
     m = orc.Mother(kind, param)
     sj = np.array(scales)
     ref = orc.cwt_rows(x, 1.0, sj, m)[:, :x.size]
-    for opts in (None, {"band_pass_a": 0}):
+    for opts in ({"narrow_big": 0}, {"narrow_big": 0, "band_pass_a": 0}):
         plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options=opts)
         W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
         assert plan.last_split()["two_pass"] == len(scales)
