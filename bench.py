@@ -185,8 +185,9 @@ def main():
     plan.set_option("overlap", opts.get("overlap", 0))
     plan.set_option("overlap_narrow", opts.get("overlap_narrow", 1 if prec == 64 else 0))
     split = plan.last_split()
-    units_by_class = {"small": split["small"] * N, "narrow": split["narrow"] * N,
-                      "pass_a": split["two_pass"] * N, "pass_b": split["two_pass"] * N}
+    units_by_class = {"small": split["small"] * N, "narrow": (split["narrow"] - split["narrow_k2048"]) * N,
+                      "narrow_big": split["narrow_k2048"] * N, "pass_a": split["two_pass"] * N,
+                      "pass_b": split["two_pass"] * N}
     kern = {}
     for name, (ms, cnt) in tm.items():
         kern[name] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}

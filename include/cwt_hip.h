@@ -194,9 +194,10 @@ int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother,
  * in *n and resets the accumulators.  Synchronises the stream.              */
 int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_ms,
                      int* launches, int* n);
-/* How the last cwt_transform_rows call split its rows: counts[0] = rows done by
- * the single-workgroup kernel, [1] = band-limited single pass, [2] = two-pass. */
-int cwt_plan_last_split(cwt_plan* plan, int counts[3]);
+/* How the last cwt_transform_rows call split its rows: counts[0] = rows done by the single-workgroup
+ * kernel, [1] = band-limited single pass with K <= 1024, [2] = two-pass, [3] = band-limited single pass
+ * with K = 2048 (fp64, 16384-point workgroups). */
+int cwt_plan_last_split(cwt_plan* plan, int counts[4]);
 
 #ifdef __cplusplus
 }

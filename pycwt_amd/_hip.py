@@ -227,9 +227,9 @@ class Plan:
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n.value, cap))}
 
     def last_split(self):
-        c = (C.c_int * 3)()
+        c = (C.c_int * 4)()
         self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
-        return {"small": c[0], "narrow": c[1], "two_pass": c[2]}
+        return {"small": c[0], "narrow": c[1] + c[3], "two_pass": c[2], "narrow_k2048": c[3]}
 
 
 class DeviceBuffer:

@@ -35,10 +35,10 @@ int fail(int code, const std::string& msg) {
       return fail(CWT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
-enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_PASS_A,
+enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_BIG, KC_PASS_A,
                    KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_COUNT };
-const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a", "fwd_pass_b", "small", "direct",
-                                           "narrow",    "pass_a",     "pass_b",     "icwt", "elementwise"};
+const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a", "fwd_pass_b", "small",  "direct", "narrow",
+                                           "narrow_big", "pass_a",    "pass_b",     "icwt",   "elementwise"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -93,7 +93,7 @@ struct cwt_plan {
   struct Group { int logK; int first; int count; int nterms; };
   std::vector<Group> narrow_groups;
   int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
-  int split[3] = {0, 0, 0};
+  int split[4] = {0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024, two-pass, band-limited K = 2048
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
@@ -335,6 +335,12 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
 }
 
 // log2 of the row length K of the two-pass factorisation N = R*K
+void set_split(cwt_plan* p) {
+  int n_big = 0;
+  for (const auto& g : p->narrow_groups) if (g.logK == 11) n_big += g.count;
+  p->split[0] = p->n_small; p->split[1] = p->n_narrow - n_big; p->split[2] = p->n_wide; p->split[3] = n_big;
+}
+
 int chunk_rows_of(const cwt_plan* p) {
   if (p->chunk_rows > 0) return p->chunk_rows;
   const size_t row_bytes = size_t(p->N) * 2 * p->esize();
@@ -389,20 +395,34 @@ bool narrow_ct_all_applies(const cwt_plan* p) {
 
 constexpr int kMaxGridY = 32768;   // rows per launch (gridDim.y is limited to 65535)
 
+// rows of the two compile-time band-limited kernels: the row table is sorted by class, groups with
+// K <= 1024 first, then (fp64 only) the K = 2048 groups
+void narrow_class_counts(const cwt_plan* p, int* n_small_k, int* n_big) {
+  *n_small_k = *n_big = 0;
+  for (const auto& g : p->narrow_groups) (g.logK == 11 ? *n_big : *n_small_k) += g.count;
+}
+
 template <typename T>
 void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
                           int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
-  // the row table is sorted by class: groups with K <= 1024 first, then (fp64) the K = 2048 groups
   const int first = p->narrow_groups.front().first;
-  int n_small_k = 0, n_big = 0;
-  for (const auto& g : p->narrow_groups) (g.logK == 11 ? n_big : n_small_k) += g.count;
+  int n_small_k, n_big;
+  narrow_class_counts(p, &n_small_k, &n_big);
   for (int r0 = 0; r0 < n_small_k; r0 += kMaxGridY)
     hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_small_k - r0)),
                        dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                        p->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
                        p->logN, W, long(ldw), long(ncols));
+}
+
+template <typename T>
+void launch_narrow_ct_big(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
+                          int64_t ncols) {
   if constexpr (sizeof(T) == 8) {
+    const int first = p->narrow_groups.front().first;
+    int n_small_k, n_big;
+    narrow_class_counts(p, &n_small_k, &n_big);
     for (int r0 = 0; r0 < n_big; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_big<T>), dim3(1u << (p->logN - 14), std::min(kMaxGridY, n_big - r0)), dim3(1024),
                          (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rows_dev + first + n_small_k + r0, mo,
@@ -608,7 +628,11 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       hipStream_t keep = p->stream;
       narrow_on_side = p->overlap_narrow && p->n_wide && !(p->overlap);
       if (narrow_on_side) p->stream = p->side[0];
-      rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      int n_small_k, n_big;
+      narrow_class_counts(p, &n_small_k, &n_big);
+      rc = CWT_OK;
+      if (n_small_k) rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      if (!rc && n_big) rc = timed_launch(p, KC_NARROW_BIG, [&] { launch_narrow_ct_big<T>(p, xhat, mo, W, ldw, ncols); });
       p->stream = keep;
       if (rc) return rc;
       if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
@@ -857,7 +881,7 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
     p->last_scales.assign(scales, scales + nrows);
     p->table_valid = true;
   }
-  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
@@ -893,7 +917,7 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), xhat_ld, total, nullptr, nullptr, nrows);
   if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
-  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols)
@@ -911,7 +935,7 @@ int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* tabl
   int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
   if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
-  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  set_split(p);
   Mother mo;
   mo.kind = MOTHER_TABLE; mo.m = 0; mo.p = 0; mo.table = table_dev;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
@@ -945,7 +969,7 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
   if (!rc) rc = upload_row_table(p);
   if (rc) return rc;
-  p->split[0] = p->n_small; p->split[1] = p->n_narrow; p->split[2] = p->n_wide;
+  set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, spec_dev, mo, nrows, W_dev, ldw, ncols)
@@ -1140,9 +1164,9 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
   return CWT_OK;
 }
 
-int cwt_plan_last_split(cwt_plan* p, int counts[3]) {
+int cwt_plan_last_split(cwt_plan* p, int counts[4]) {
   if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
-  counts[0] = p->split[0]; counts[1] = p->split[1]; counts[2] = p->split[2];
+  for (int i = 0; i < 4; ++i) counts[i] = p->split[i];
   return CWT_OK;
 }
 

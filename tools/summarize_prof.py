@@ -24,6 +24,8 @@ def short(name):
 
 
 def klass(name):
+    if name.startswith("k_narrow_ct_big"):
+        return "narrow_big"
     for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
         if name.startswith(k):
             fwd = name.rstrip(">").endswith(", 1") or name.rstrip(">").endswith("true")
