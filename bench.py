@@ -183,7 +183,7 @@ def main():
     tm = plan.timings()
     plan.set_option("profile", 0)
     plan.set_option("overlap", opts.get("overlap", 0))
-    plan.set_option("overlap_narrow", opts.get("overlap_narrow", 1 if prec == 64 else 0))
+    plan.set_option("overlap_narrow", opts.get("overlap_narrow", 0))
     split = plan.last_split()
     units_by_class = {"small": split["small"] * N, "narrow": (split["narrow"] - split["narrow_k2048"]) * N,
                       "narrow_big": split["narrow_k2048"] * N, "pass_a": split["two_pass"] * N,

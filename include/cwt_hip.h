@@ -74,7 +74,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  streams; 0 (default) = strictly one after the other
  *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
  *   "overlap_narrow" 1 = queue the band-limited rows on a side stream beside the two-pass chain
- *                  (default for fp64), 0 = everything on the plan's stream
+ *                  (+2 % in fp64), 0 (default) = everything on the plan's stream
  *   "band_pass_a"  0 = always run the full column FFT in pass A (no short aliased column FFTs)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */

@@ -68,7 +68,8 @@ struct cwt_plan {
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
-  int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain
+  int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain (measured: +2 % in
+                           // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   // device resources
@@ -726,7 +727,6 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->prec = precision;
   p->max_rows = max_rows;
   p->log_wg_points = precision == 64 ? 13 : 14;
-  p->overlap_narrow = precision == 64;   // measured: +2 % in fp64, -3 % in fp32
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
