@@ -70,7 +70,8 @@ def test_mid_golden_two_pass(hip_library, name):
     g = load_golden("mid_" + name)
     x = np.random.default_rng(int(g["seed"])).standard_normal(int(g["N"]))
     kind, param = MOTHERS[name]
-    for opts in (None, {"narrow": 0}, {"chunk_rows": 1}, {"wg_points": 4096}, {"lmax": 256}):
+    for opts in (None, {"narrow": 0}, {"chunk_rows": 1}, {"wg_points": 4096}, {"lmax": 256},
+                 {"narrow": 0, "chunk_rows": 2, "overlap": 1}, {"overlap_narrow": 1}, {"ct": 0}):
         plan = _hip.Plan(int(g["N"]), 64, max_rows=32, options=opts)
         W, _ = plan.execute_host(x, kind, param, 1.0, g["sj"])
         plan.close()
@@ -404,3 +405,25 @@ def test_config5_deterministic_part_at_full_size(hip_library):
     o = orc.Mother(orc.MORLET, 6)
     ref = orc.cwt_rows(y1n, dt, sj[[5]], o) * orc.cwt_rows(y2n, dt, sj[[5]], o).conj()
     assert np.abs(W12[5] - ref[0]).max() < 1e-10 * np.abs(ref).max()
+
+
+def test_stream_overlap_options_keep_parity_at_full_size(hip_library):
+    """The optional side-stream pipelines (pass A of chunk c+1 beside pass B of chunk c through two
+    intermediate buffers; band-limited rows beside the two-pass chain) must not change a single bit."""
+    N = 1 << 20
+    x = np.random.default_rng(77).standard_normal(N)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 256)[:160:4]                     # 40 rows, mostly two-pass
+    base = None
+    for opts in (None, {"overlap": 1, "chunk_rows": 3}, {"overlap_narrow": 1}, {"overlap": 1, "chunk_rows": 5}):
+        plan = _hip.Plan(N, 64, max_rows=64, options=opts)
+        for _ in range(3):                                # repeated calls re-use the two buffers
+            W = _device_rows(plan, x, orc.MORLET, 6, sj, N)
+        plan.close()
+        if base is None:
+            base = W
+            ref = orc.cwt_rows(x, 1.0, sj[[0, 13, 39]], m)
+            per_row, _ = row_errors(W[[0, 13, 39]], ref)
+            assert per_row.max() < TOL[64]
+        else:
+            assert np.array_equal(W, base), opts
