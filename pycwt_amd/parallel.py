@@ -134,3 +134,33 @@ def icwt_sharded(W_local, sj_local, dt, dj=1 / 12, wavelet="morlet", *, group=No
         return None
     total = part.cpu().numpy().astype(np.float64)
     return dj * np.sqrt(dt) / (mother.cdelta * mother.psi(0)) * total
+
+
+def wct_significance_sharded(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
+                             *, group=None, precision=64, device_index=None, seed=None):
+    """Monte-Carlo coherence significance with the surrogate draws split over the ranks:
+    every rank simulates ~mc_count/G AR(1) pairs on its GPU, the per-scale histograms (rows x 1000) are
+    summed with ONE all-reduce, and every rank evaluates the same percentiles.  Returns the array of
+    `pycwt.wct_significance` (no disk cache here)."""
+    import torch
+    import torch.distributed as dist
+    from . import wavelet as _w
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mother = _check_parameter_wavelet(wavelet)
+    if device_index is None:
+        device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if seed is not None:
+        np.random.seed(seed + rank)                       # independent surrogates per rank
+    N, sj, outside, rows_with_data, maxscale = _w._mc_setup(mother, dt, dj, s0, J)
+    mine = len(range(rank, mc_count, world))
+    hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index)
+    if world > 1:
+        backend = dist.get_backend(group)
+        t = torch.from_numpy(hist)
+        if backend == "nccl":
+            t = t.to(torch.device("cuda", device_index))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        hist = t.cpu().numpy()
+    return _w._mc_percentiles(hist, rows_with_data, maxscale, significance_level)

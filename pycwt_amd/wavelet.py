@@ -503,35 +503,24 @@ def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, w
     return WCT, aWCT, coi, freq, sig
 
 
-def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
-                     progress=True, cache=True, *, precision=None, device=0):
-    """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of AR(1)
-    surrogates, coherence of each pair on the GPU, per-scale histogram of the values outside the cone
-    of influence, `significance_level` percentile.  Scales that never leave the COI get NaN.  Results
-    are cached in the reference's file format under `get_cache_dir()`.  Statistical parity only (the
-    reference draws from the unseeded global RNG, helpers.py:170)."""
-    mother = _check_parameter_wavelet(wavelet)
-    precision = _default_precision() if precision is None else int(precision)
-    if cache:
-        with np.errstate(invalid="ignore", divide="ignore"):      # |4*al| > 1 gives nan, as in the reference
-            aa = np.round(np.arctanh(np.array([al1, al2]) * 4))
-        aa = np.abs(aa) + 0.5 * (aa < 0)
-        path = os.path.join(get_cache_dir(), "wct_sig_{:0.5f}_{:0.5f}_{:0.5f}_{:0.5f}_{:d}_{}.gz".format(
-            aa[0], aa[1], dj, s0 / dt, int(J), mother.name))
-        if os.path.exists(path):
-            return np.loadtxt(path, unpack=True)
+_MC_BINS = 1000
+
+
+def _mc_setup(mother, dt, dj, s0, J):
+    """Geometry of the Monte-Carlo surrogates (wavelet.py:591-606): series length 6*s_max/dt, scales, the
+    mask of points outside the cone of influence, and the last scale that has any."""
     N = int(np.ceil(s0 * (2 ** (J * dj)) / dt * 6))
     sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-    period = mother.flambda() * sj
-    coi = mother.flambda() * mother.coi() * dt * (N / 2 - np.abs(np.arange(0, N) - (N - 1) / 2))
-    outside = period[:, None] <= coi[None, :]
+    outside = (mother.flambda() * sj)[:, None] <= _coi(mother, N, dt)[None, :]
     rows_with_data = outside.any(axis=1)
-    sig95 = np.zeros(J + 1)
-    sig95[rows_with_data] = np.nan
-    maxscale = find(rows_with_data)[-1]
-    nbins = 1000
-    hist = np.zeros((J + 1, nbins))
-    it = range(mc_count)
+    return N, sj, outside, rows_with_data, find(rows_with_data)[-1]
+
+
+def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False):
+    """Per-scale histograms (1000 bins on [0, 1)) of the coherence of `draws` AR(1) surrogate pairs, taken
+    outside the COI (wavelet.py:609-630, vectorised).  The coherence runs on the GPU."""
+    hist = np.zeros((sj.size, _MC_BINS))
+    it = range(draws)
     if progress:
         try:
             from tqdm import tqdm
@@ -542,13 +531,49 @@ def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="
         r2, _ = _coherence_on_device(rednoise(N, al1, 1), rednoise(N, al2, 1), dt, dj, sj, mother, precision,
                                      device, want_angle=False)
         for s in range(maxscale):
-            v = np.floor(r2[s, outside[s]] * nbins).astype(int)
-            hist[s] += np.bincount(v[(v >= 0) & (v < nbins)], minlength=nbins)
-    centres = (np.arange(nbins) + 0.5) / nbins
+            v = np.floor(r2[s, outside[s]] * _MC_BINS).astype(int)
+            hist[s] += np.bincount(v[(v >= 0) & (v < _MC_BINS)], minlength=_MC_BINS)
+    return hist
+
+
+def _mc_percentiles(hist, rows_with_data, maxscale, significance_level):
+    """wavelet.py:632-640: the `significance_level` quantile of every scale's histogram; scales inside
+    the COI everywhere stay 0, scales beyond the last resolvable one NaN."""
+    sig = np.zeros(hist.shape[0])
+    sig[rows_with_data] = np.nan
+    centres = (np.arange(_MC_BINS) + 0.5) / _MC_BINS
     for s in range(maxscale):
         sel = hist[s] > 0
         cum = hist[s, sel].cumsum()
-        sig95[s] = np.interp(significance_level, (cum - 0.5) / cum[-1], centres[sel])
+        sig[s] = np.interp(significance_level, (cum - 0.5) / cum[-1], centres[sel])
+    return sig
+
+
+def _mc_cache_path(al1, al2, dt, dj, s0, J, mother):
+    with np.errstate(invalid="ignore", divide="ignore"):      # |4*al| > 1 gives nan, as in the reference
+        aa = np.round(np.arctanh(np.array([al1, al2]) * 4))
+    aa = np.abs(aa) + 0.5 * (aa < 0)
+    return os.path.join(get_cache_dir(), "wct_sig_{:0.5f}_{:0.5f}_{:0.5f}_{:0.5f}_{:d}_{}.gz".format(
+        aa[0], aa[1], dj, s0 / dt, int(J), mother.name))
+
+
+def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
+                     progress=True, cache=True, *, precision=None, device=0):
+    """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of AR(1)
+    surrogates, coherence of each pair on the GPU, per-scale histogram of the values outside the cone
+    of influence, `significance_level` percentile.  Scales that never leave the COI get NaN.  Results
+    are cached in the reference's file format under `get_cache_dir()`.  Statistical parity only (the
+    reference draws from the unseeded global RNG, helpers.py:170).  `pycwt_amd.parallel.
+    wct_significance_sharded` splits the draws over the GPUs of a node."""
+    mother = _check_parameter_wavelet(wavelet)
+    precision = _default_precision() if precision is None else int(precision)
+    path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother) if cache else None
+    if cache and os.path.exists(path):
+        return np.loadtxt(path, unpack=True)
+    N, sj, outside, rows_with_data, maxscale = _mc_setup(mother, dt, dj, s0, J)
+    hist = _mc_histogram(mc_count, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device,
+                         progress)
+    sig95 = _mc_percentiles(hist, rows_with_data, maxscale, significance_level)
     if cache:
         np.savetxt(path, sig95)
     return sig95

@@ -83,6 +83,51 @@ def test_two_ranks_shard_broadcast_and_reduce(tmp_path):
     assert r1["iw"].size == 0
 
 
+def _mc_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import build_emu
+    from pycwt_amd import _hip, parallel
+    _hip._default = _hip.Library(build_emu.build())      # test infrastructure: kernels on the CPU emulation
+    sig = parallel.wct_significance_sharded(0.3, 0.5, dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=10, seed=100)
+    np.save(os.path.join(tmpdir, f"mc{rank}.npy"), sig)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_monte_carlo_draws_sharded_with_one_allreduce(tmp_path):
+    """Config 5's Monte-Carlo part: draws split over 2 ranks, histograms all-reduced; both ranks must end
+    with the same percentiles, and they must equal a single-rank run over the same 10 surrogate pairs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()                                     # build once, before the workers race for it
+    port = _free_port()
+    mp.spawn(_mc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "mc0.npy"), np.load(tmp_path / "mc1.npy")
+    np.testing.assert_allclose(a, b, equal_nan=True)
+    ok = np.isfinite(a)
+    assert ok.any() and (a[ok] > 0.2).all() and (a[ok] <= 1).all()
+    # same surrogates in one process: rank r used seed 100 + r for its 5 draws
+    from pycwt_amd import _hip, wavelet
+    _hip._default = _hip.Library(build_emu.build())
+    try:
+        m = wavelet._check_parameter_wavelet("morlet")
+        N, sj, outside, rows, maxscale = wavelet._mc_setup(m, 1.0, 0.5, 2.0, 6)
+        hist = 0
+        for r in range(2):
+            np.random.seed(100 + r)
+            hist = hist + wavelet._mc_histogram(5, 0.3, 0.5, 1.0, 0.5, sj, N, outside, maxscale, m, 64, 0)
+        np.testing.assert_allclose(wavelet._mc_percentiles(hist, rows, maxscale, 0.95), a, equal_nan=True)
+    finally:
+        _hip._default = None
+        for p in wavelet._plans.values():
+            p.close()
+        wavelet._plans.clear()
+
+
 def test_shard_rows_partition():
     from pycwt_amd.parallel import shard_rows
     for n in (1, 7, 256):
