@@ -97,6 +97,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    from pycwt_amd import _build
+    _build.ensure(local)          # prebuilt library travels with the tree; compile once if it did not
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist

@@ -41,5 +41,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def ensure(local_rank: int = 0, timeout_s: float = 600.0) -> str:
+    """Make sure the library exists when several ranks start at once on a box that did not receive
+    a prebuilt one: local rank 0 compiles to a temporary name and renames it into place, the other
+    ranks wait for the file.  An existing library is used as is (no mtime check: a snapshot copy
+    does not preserve mtimes)."""
+    import time
+    if os.path.exists(OUT):
+        return OUT
+    if local_rank == 0:
+        tmp = OUT + f".tmp{os.getpid()}"
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + SOURCES + ["-o", tmp]
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, OUT)
+        return OUT
+    t0 = time.time()
+    while not os.path.exists(OUT):
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError(f"{OUT} was not built by local rank 0 within {timeout_s:.0f} s")
+        time.sleep(0.5)
+    return OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
