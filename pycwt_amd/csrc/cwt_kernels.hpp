@@ -422,6 +422,20 @@ __device__ __forceinline__ void transpose_store(T (&re)[16], T (&im)[16], T* lds
   (void)NT;
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (id & 7).  The kernels below store 128-B segments at
+// a 16-KiB stride, neighbouring segments coming from neighbouring tiles; with the natural map every XCD's
+// L2 owns every 8th line of each run.  This map gives XCD c the contiguous tile range
+// [c n/8, (c+1) n/8) instead, so one L2 writes back whole multi-KiB runs (measured on the store
+// pattern alone: 5.46 -> 5.76 TB/s, tools/microbench/mem_patterns.hip).
+// In the transform itself it pays for complex128 only (A/B on one box: pass B -3 %, band-limited -2 %;
+// complex64 pass B +6 %, pass A +3 % in either precision), so only those kernels use it.
+template <typename T>
+__device__ __forceinline__ unsigned xcd_tile() {
+  const unsigned x = blockIdx.x, n = gridDim.x;
+  if (sizeof(T) != 8 || (n & 7u)) return x;
+  return (x & 7u) * (n >> 3) + (x >> 3);
+}
+
 template <typename T, int LOGK, int LOGP, int NTERMS>
 __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
                                                const Mother& mo, const cplx<T>* __restrict__ tw_all,
@@ -437,7 +451,7 @@ __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat,
   F f;
   f.t = threadIdx.x & ((1 << LOGTB) - 1);
   f.j = threadIdx.x >> LOGTB;
-  const unsigned r = (blockIdx.x << LOGTB) + f.t;
+  const unsigned r = (xcd_tile<T>() << LOGTB) + f.t;
 
   // Input of the K-point FFT for output residue r (n = R m + r):
   //   Z_r[q] = sum_{i < nterms} Y[k_i(q)] e^{2 pi i k_i(q) r / N},  k_i(q) = k_lo + ((q - k_lo) mod K) + i K
@@ -706,7 +720,7 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
   F f;
   f.j = threadIdx.x & (NT - 1);
   f.t = threadIdx.x >> LOGNT;
-  const unsigned r0 = blockIdx.x << LOGTB;
+  const unsigned r0 = xcd_tile<T>() << LOGTB;
   const cplx<T>* z = Z + (long(blockIdx.y) << logN) + (long(r0) << LOGK);
   const unsigned zoff = (unsigned(f.t) << LOGK) + f.j;
   T re[16], im[16];

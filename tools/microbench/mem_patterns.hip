@@ -42,6 +42,28 @@ __global__ void k_seg(double2* W, int logN, int logK, double v) {
   for (int m = j; m < K; m += NT) row[(size_t(m) << logR) + r0 + t] = make_double2(v + m, v - t);
 }
 
+// k_seg with (a) optional non-temporal stores and (b) an XCD-aware tile map: workgroup ids go round-robin
+// over the 8 XCDs, so tile x' = (x & 7) * (tiles/8) + (x >> 3) gives every XCD one contiguous eighth of
+// each output row (its L2 then owns whole 2-KiB runs instead of every 8th 128-B line).
+template <int LOGT, bool NT_STORE, bool XCD>
+__global__ void k_seg2(double2* W, int logN, int logK, double v) {
+  typedef double v2 __attribute__((vector_size(16)));
+  const int T = 1 << LOGT;
+  const int logR = logN - logK;
+  const int t = threadIdx.x & (T - 1), j = threadIdx.x >> LOGT;
+  const int NTH = blockDim.x >> LOGT;
+  unsigned x = blockIdx.x;
+  if (XCD) x = (x & 7) * (gridDim.x >> 3) + (x >> 3);
+  const size_t r0 = size_t(x) << LOGT;
+  double2* row = W + (size_t(blockIdx.y) << logN);
+  const int K = 1 << logK;
+  for (int m = j; m < K; m += NTH) {
+    double2* q = row + (size_t(m) << logR) + r0 + t;
+    if (NT_STORE) { v2 w = {v + m, v - t}; __builtin_nontemporal_store(w, reinterpret_cast<v2*>(q)); }
+    else *q = make_double2(v + m, v - t);
+  }
+}
+
 // "one FFT per wavefront" store pattern: wave w of the workgroup owns residue r0 + w, lane l slot e owns
 // output m = l + 64 e: every store instruction writes 64 separate 16-B pieces; the neighbouring pieces
 // of each 128-B line come from the other 7 waves of the SAME workgroup (same CU, same L2).
@@ -105,6 +127,16 @@ int main() {
     snprintf(nm, 64, "seg T=64 (1KiB) K=2^%d", logK);
     bench(nm, n * 16.0, [&] { hipLaunchKernelGGL(k_seg<6>, dim3(N >> (logK + 6), rows), dim3(512), 0, 0, A, int(logN), logK, 1.0); });
   }
+  bench("seg2 128B plain", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, false, false>), dim3(N >> 13, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 128B plain xcd", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, false, true>), dim3(N >> 13, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 128B nt", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, true, false>), dim3(N >> 13, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 128B nt xcd", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, true, true>), dim3(N >> 13, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 64B nt", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<2, true, false>), dim3(N >> 12, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 64B nt xcd", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<2, true, true>), dim3(N >> 12, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 64B plain xcd", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<2, false, true>), dim3(N >> 12, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 256B nt xcd", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<4, true, true>), dim3(N >> 14, rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
+  bench("seg2 128B nt xcd K=2^11", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, true, true>), dim3(N >> 14, rows), dim3(1024), 0, 0, A, int(logN), 11, 1.0); });
+  bench("seg2 128B nt     K=2^11", n * 16.0, [&] { hipLaunchKernelGGL((k_seg2<3, true, false>), dim3(N >> 14, rows), dim3(1024), 0, 0, A, int(logN), 11, 1.0); });
   bench("seg per-wave 16B pieces K=2^10", n * 16.0, [&] { hipLaunchKernelGGL(k_seg_wave, dim3(N >> (10 + 3), rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
   bench("seg per-wave 16B + barrier", n * 16.0, [&] { hipLaunchKernelGGL(k_seg_wave_sync, dim3(N >> (10 + 3), rows), dim3(512), 0, 0, A, int(logN), 10, 1.0); });
   // write S MiB then read it back; time of the read only (events around the read), min of 5
