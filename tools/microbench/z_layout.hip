@@ -51,6 +51,55 @@ __global__ void __launch_bounds__(512) k_b(const double2* __restrict__ Z, double
   }
 }
 
+// pass B of layout RQ plus NX LDS exchanges shaped like the FFT's (per plane: 16 b64 writes, wave barrier,
+// 16 b64 reads at the transposed, padded index) -- no arithmetic: how much of the real kernel's time is LDS?
+template <int NX, bool B128>
+__global__ void __launch_bounds__(512) k_b_lds(const double2* __restrict__ Z, double2* __restrict__ W) {
+  extern __shared__ double2 lds_raw[];
+  double* lds = reinterpret_cast<double*>(lds_raw);
+  unsigned x = blockIdx.x;
+  x = (x & 7) * (gridDim.x >> 3) + (x >> 3);
+  const double2* z = Z + (size_t(blockIdx.y) << 20);
+  double2* w = W + (size_t(blockIdx.y) << 20);
+  double2 acc[16];
+  const int t = threadIdx.x & 7, j = threadIdx.x >> 3;
+  const int jj = threadIdx.x & 63, tt = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = z[((x * 8 + tt) << 10) + jj + 64 * e];
+  auto pad = [](int a) { return a + (a >> 4); };
+#pragma unroll
+  for (int xch = 0; xch < NX; ++xch) {
+    if (B128) {
+      double2* l2 = lds_raw + tt * 1088;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) l2[pad(jj + 64 * e)] = acc[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = l2[pad(jj * 16 + e)];
+      __syncthreads();
+    } else {
+      double* l = lds + tt * 1088;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) l[pad(jj + 64 * e)] = acc[e].x;
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e].x = l[pad(jj * 16 + e)];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) l[pad(jj + 64 * e)] = acc[e].y;
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e].y = l[pad(jj * 16 + e)];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    v2 v = {acc[e].x, acc[e].y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2*>(w + (unsigned(j + 64 * e) << 10) + x * 8 + t));
+  }
+}
+
 int main() {
   const int rows = 12, chunks = 9;
   const size_t N = size_t(1) << 20;
@@ -82,5 +131,12 @@ int main() {
   run("A+B Z[r][q] xcd", a_rq, [&](double2* w) { hipLaunchKernelGGL((k_b<false, true>), g, blk, 0, 0, Z, w); });
   run("A+B Z[q][r]", a_qr, [&](double2* w) { hipLaunchKernelGGL((k_b<true, false>), g, blk, 0, 0, Z, w); });
   run("A+B Z[q][r] xcd", a_qr, [&](double2* w) { hipLaunchKernelGGL((k_b<true, true>), g, blk, 0, 0, Z, w); });
+  const size_t l64 = 8 * 1088 * 8, l128 = 8 * 1088 * 16;
+  run("pass B + 1 LDS exchange (b64)", nop, [&](double2* w) { hipLaunchKernelGGL((k_b_lds<1, false>), g, blk, l64, 0, Z, w); });
+  run("pass B + 2 LDS exchanges (b64)", nop, [&](double2* w) { hipLaunchKernelGGL((k_b_lds<2, false>), g, blk, l64, 0, Z, w); });
+  run("pass B + 3 LDS exchanges (b64)", nop, [&](double2* w) { hipLaunchKernelGGL((k_b_lds<3, false>), g, blk, l64, 0, Z, w); });
+  run("pass B + 3 LDS exchanges, 1 WG/CU", nop, [&](double2* w) { hipLaunchKernelGGL((k_b_lds<3, false>), g, blk, 100 * 1024, 0, Z, w); });
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_b_lds<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  run("pass B + 3 LDS exchanges (b128)", nop, [&](double2* w) { hipLaunchKernelGGL((k_b_lds<3, true>), g, blk, l128, 0, Z, w); });
   return 0;
 }
