@@ -67,6 +67,7 @@ struct cwt_plan {
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
   int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain (measured: +2 % in
                            // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
@@ -444,6 +445,15 @@ template <typename T, int LOGR>
 void launch_pass_a_ct_rows(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
                            cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
+  if constexpr (LOGR <= 10) {
+    if (p->pass_a_small) {
+      constexpr int LP = LOGP - 1;
+      hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
+                         (size_t(1) << LP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
+                         static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LOGP>), dim3(1u << (p->logN - LOGP), cnt), dim3(1 << (LOGP - 4)),
                      (size_t(1) << LOGP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
                      static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
@@ -796,6 +806,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
+  else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);

@@ -429,11 +429,19 @@ __device__ __forceinline__ void transpose_store(T (&re)[16], T (&im)[16], T* lds
 // pattern alone: 5.46 -> 5.76 TB/s, tools/microbench/mem_patterns.hip).
 // In the transform itself it pays for complex128 only (A/B on one box: pass B -3 %, band-limited -2 %;
 // complex64 pass B +6 %, pass A +3 % in either precision), so only those kernels use it.
+__device__ __forceinline__ unsigned xcd_tile_any() {
+  const unsigned x = blockIdx.x, n = gridDim.x;
+  return (n & 7u) ? x : (x & 7u) * (n >> 3) + (x >> 3);
+}
 template <typename T>
 __device__ __forceinline__ unsigned xcd_tile() {
-  const unsigned x = blockIdx.x, n = gridDim.x;
-  if (sizeof(T) != 8 || (n & 7u)) return x;
-  return (x & 7u) * (n >> 3) + (x >> 3);
+  return sizeof(T) == 8 ? xcd_tile_any() : blockIdx.x;
+}
+// Pass A on half-size tiles stores 64-B segments with plain stores; those only merge into whole lines when
+// both halves meet in one L2, i.e. under the XCD-aware map (store pattern alone: 3.9 -> 4.8 TB/s).
+template <typename T, int LOGTQ>
+__device__ __forceinline__ unsigned pass_a_tile() {
+  return ((2 * sizeof(T)) << LOGTQ) == 64 ? xcd_tile_any() : blockIdx.x;
 }
 
 template <typename T, int LOGK, int LOGP, int NTERMS>
@@ -559,7 +567,7 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
   F f;
   f.t = threadIdx.x & ((1 << LOGTQ) - 1);
   f.j = threadIdx.x >> LOGTQ;
-  const unsigned q = (blockIdx.x << LOGTQ) + f.t;
+  const unsigned q = (pass_a_tile<T, LOGP - LOGR>() << LOGTQ) + f.t;
   const unsigned k0 = q + (unsigned(f.j) << logK);        // bin of slot 0; slot e adds (e*NT) << logK
   T re[16], im[16];
   if constexpr (MODE == IN_REAL) {
@@ -622,7 +630,7 @@ __device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xha
   f.j = threadIdx.x >> LOGTB;
   const int tq = f.t & (TQ - 1);
   const unsigned rp = unsigned(f.t) >> LOGTQ;                       // residue r' < R2
-  const int q0 = blockIdx.x << LOGTQ;
+  const int q0 = pass_a_tile<T, LOGP - LOGR>() << LOGTQ;
 
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);                 // [a][tq], a < C
   for (int idx = threadIdx.x; idx < (C << LOGTQ); idx += (1 << (LOGP - 4))) {
@@ -687,7 +695,7 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
   F f;
   f.t = threadIdx.x & ((1 << LOGTQ) - 1);
   f.j = threadIdx.x >> LOGTQ;
-  const unsigned q = (blockIdx.x << LOGTQ) + f.t;
+  const unsigned q = (pass_a_tile<T, LOGP - LOGR>() << LOGTQ) + f.t;
   const unsigned k0 = q + (unsigned(f.j) << logK);
   T re[16], im[16];
 #pragma unroll
