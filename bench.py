@@ -214,6 +214,10 @@ def main():
                            "FETCH_SIZE x2 + WRITE_SIZE)") if traffic else None,
         "avg_launch_ms": dom_avg_ms, "launches_per_step": dom_launches,
         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+        # bytes the memory system really moved per launch (PMC) / live launch time: how busy HBM + fabric are,
+        # as opposed to `frac`, which prices only the algorithmic bytes
+        "traffic_GBs": (traffic / (dom_avg_ms * 1e-3) / 1e9) if traffic else None,
+        "traffic_frac": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "whole_path": {"algorithmic_bytes_per_step_per_gpu": alg_bytes_total,
                        "kernel_ms_per_step": gpu_ms,
                        "achieved_GBs": alg_bytes_total / (gpu_ms * 1e-3) / 1e9,
