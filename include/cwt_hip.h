@@ -77,6 +77,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  (+2 % in fp64), 0 (default) = everything on the plan's stream
  *   "band_pass_a"  0 = always run the full column FFT in pass A (no short aliased column FFTs)
  *   "pass_a_small" 0 = pass A on full-size workgroup tiles (default 1: half-size tiles, 4 per CU)
+ *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
