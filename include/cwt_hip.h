@@ -181,6 +181,16 @@ int cwt_reduce_scales(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t nc
 int cwt_time_mean_power(cwt_plan* plan, const void* W_dev, int64_t ldw, int64_t ncols, int nrows,
                         void* out_dev);
 
+/* Monte-Carlo significance of the coherence (pycwt/wavelet.py:609-630, the `wlc` counter):
+ *   hist[j, b] += #{ n in [lo[j], hi[j]) : floor(R2[j, n] * nbins) == b },  0 <= b < nbins,
+ * NaNs and values outside [0, 1) are skipped (the reference would raise on R2 == 1).  [lo[j], hi[j]) is the
+ * part of row j outside the cone of influence (contiguous: the COI is a triangle).  r2_dev: nrows x ld reals of
+ * the plan's precision; lo_dev / hi_dev: nrows int64 on the device; max_span >= max_j (hi[j] - lo[j]) sizes the
+ * launch; hist_dev: nrows x nbins uint64 on the device, accumulated across calls (zero it before the first).  */
+int cwt_coherence_histogram(cwt_plan* plan, const void* r2_dev, int64_t ld, int nrows,
+                            const int64_t* lo_dev, const int64_t* hi_dev, int64_t max_span, int nbins,
+                            uint64_t* hist_dev);
+
 /* ---- host convenience: what the ctypes shim of pycwt.cwt() calls ---------
  * x_host: n0 reals of the plan's precision.  W_host: nrows x n0 complex (may be
  * NULL).  xhat_host: nfft complex (may be NULL) for the 5th return value

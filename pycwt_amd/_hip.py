@@ -49,6 +49,7 @@ SYMBOLS = [
     ("cwt_reduce_scales", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.c_int,
                                     C.c_double, _P]),
     ("cwt_time_mean_power", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _P]),
+    ("cwt_coherence_histogram", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, C.c_int64, C.c_int, _P]),
     ("cwt_execute_host", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    C.POINTER(C.c_double), C.c_int, _P, _P]),
     ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
@@ -204,6 +205,11 @@ class Plan:
 
     def time_mean_power(self, W_dev: int, ldw: int, ncols: int, nrows: int, out_dev: int):
         self.lib.check(self.lib.cwt_time_mean_power(self.h, _P(W_dev), ldw, ncols, nrows, _P(out_dev)))
+
+    def coherence_histogram(self, r2_dev: int, ld: int, nrows: int, lo_dev: int, hi_dev: int, max_span: int,
+                            nbins: int, hist_dev: int):
+        self.lib.check(self.lib.cwt_coherence_histogram(self.h, _P(r2_dev), ld, nrows, _P(lo_dev), _P(hi_dev),
+                                                        int(max_span), nbins, _P(hist_dev)))
 
     # -- host convenience --
     def execute_host(self, x, mother: int, param: float, dt: float, scales, want_W=True, want_xhat=True):

@@ -1137,6 +1137,27 @@ int cwt_time_mean_power(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t nco
   });
 }
 
+int cwt_coherence_histogram(cwt_plan* p, const void* r2_dev, int64_t ld, int nrows, const int64_t* lo_dev,
+                            const int64_t* hi_dev, int64_t max_span, int nbins, uint64_t* hist_dev) {
+  if (!p || !r2_dev || !lo_dev || !hi_dev || !hist_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || ld < 1 || nbins < 1 || nbins > 16384 || max_span < 0) return fail(CWT_EINVAL, "bad shape");
+  if (max_span == 0) return CWT_OK;
+  HIPCHECK(hipSetDevice(p->device));
+  static_assert(sizeof(long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "LP64 expected");
+  const unsigned gx = unsigned(std::min<int64_t>(512, (max_span + 4095) / 4096));   // >= 16 columns per thread
+  const size_t lds = size_t(nbins) * sizeof(unsigned);
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    if (p->prec == 64)
+      hipLaunchKernelGGL((k_coherence_hist<double>), dim3(gx, nrows), dim3(256), lds, p->stream,
+                         static_cast<const double*>(r2_dev), long(ld), reinterpret_cast<const long*>(lo_dev),
+                         reinterpret_cast<const long*>(hi_dev), nbins, reinterpret_cast<unsigned long long*>(hist_dev));
+    else
+      hipLaunchKernelGGL((k_coherence_hist<float>), dim3(gx, nrows), dim3(256), lds, p->stream,
+                         static_cast<const float*>(r2_dev), long(ld), reinterpret_cast<const long*>(lo_dev),
+                         reinterpret_cast<const long*>(hi_dev), nbins, reinterpret_cast<unsigned long long*>(hist_dev));
+  });
+}
+
 int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, double param, double dt,
                      const double* scales, int nrows, void* W_host, void* xhat_host) {
   if (!p || !x_host || !scales) return fail(CWT_EINVAL, "NULL argument");

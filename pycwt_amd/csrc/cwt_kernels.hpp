@@ -821,6 +821,28 @@ __global__ void k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int 
   out[n] = coeff * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
+// Monte-Carlo significance of the coherence (pycwt/wavelet.py:609-630): per-scale histogram of floor(R2 * nbins)
+// over the columns [lo_j, hi_j) that lie outside the cone of influence; values outside [0, nbins) and NaNs are
+// skipped.  One LDS histogram per workgroup, merged into the global one (accumulated over the draws).
+template <typename T>
+__global__ void k_coherence_hist(const T* __restrict__ R2, long ld, const long* __restrict__ lo,
+                                 const long* __restrict__ hi, int nbins, unsigned long long* __restrict__ hist) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  unsigned* h = reinterpret_cast<unsigned*>(lds_raw);
+  const int row = blockIdx.y;
+  for (int b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0u;
+  __syncthreads();
+  const T* r = R2 + long(row) * ld;
+  const long stop = hi[row];
+  for (long n = lo[row] + long(blockIdx.x) * blockDim.x + threadIdx.x; n < stop; n += long(gridDim.x) * blockDim.x) {
+    const T v = floor(r[n] * T(nbins));
+    if (v >= T(0) && v < T(nbins)) atomicAdd(&h[int(v)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += blockDim.x)
+    if (h[b]) atomicAdd(&hist[long(row) * nbins + b], (unsigned long long)h[b]);
+}
+
 // k_time_mean: out[j] = (1/ncols) sum_n |W[j, n]|^2  -- the global wavelet spectrum (power.mean(axis=1),
 // sample/simple_sample.py:79).  One workgroup of 256 threads per row, fp64 accumulation.
 template <typename T>

@@ -422,6 +422,15 @@ class _Scratch:
         self.bufs.append(b)
         return b
 
+    def named(self, key, nbytes):
+        """A buffer that survives until free(): the Monte-Carlo loop re-uses its ~10 work matrices per draw
+        instead of allocating and freeing tens of GB every time."""
+        cache = self.__dict__.setdefault("cache", {})
+        b = cache.get(key)
+        if b is None or b.nbytes < nbytes:
+            b = cache[key] = self.new(nbytes)
+        return b
+
     def free(self):
         for b in self.bufs:
             b.free()
@@ -439,35 +448,44 @@ def _smooth_on_device(plan, mother, T, rows, n, dt, dj, sj, spec, tmp, out):
     plan.boxcar_scales(tmp.ptr, rows, n, n, win, out.ptr)
 
 
-def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_angle=True):
+def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_angle=True, consume=None,
+                         pool=None):
     """|S12|^2/(S1 S2) and arg(W1 conj W2) for two equally long series, all on the GPU; only the two
-    real result matrices cross PCIe."""
+    real result matrices cross PCIe.  With `consume(plan, r2_buffer, rows, n0)` the coherence stays on the
+    device and is handed to that callback instead (Monte-Carlo histogram)."""
     n0 = len(x1)
     N = _next_pow2(n0)
     rows = len(sj)
     kind, param = _device_id(mother)
     plan = _plan(N, precision, device, rows)
     es = np.dtype(plan.real).itemsize
-    sc = _Scratch(device)
+    sc = _Scratch(device) if pool is None else pool
+    names = iter(range(100))
+    alloc = (lambda nbytes: sc.new(nbytes)) if pool is None else (lambda nbytes: sc.named(next(names), nbytes))
     try:
-        xd, xh = sc.new(n0 * es), sc.new(N * 2 * es)
-        W1, W2 = sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * 2 * es)
+        xd, xh = alloc(n0 * es), alloc(N * 2 * es)
+        W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
         for x, W in ((x1, W1), (x2, W2)):
             xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
             plan.forward_fft(xd.ptr, n0, xh.ptr)
             plan.transform_rows(xh.ptr, kind, param, dt, sj, W.ptr, n0, n0)
-        P, Cx, ang = sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * 2 * es), sc.new(rows * n0 * es)
+        P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
         plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
-        spec = sc.new(rows * N * 2 * es)
-        tmp, S, S12 = W1, W2, sc.new(rows * n0 * 2 * es)            # W1/W2 are dead after the products
+        spec = alloc(rows * N * 2 * es)
+        tmp, S, S12 = W1, W2, alloc(rows * n0 * 2 * es)             # W1/W2 are dead after the products
         _smooth_on_device(plan, mother, P, rows, n0, dt, dj, sj, spec, tmp, S)
         _smooth_on_device(plan, mother, Cx, rows, n0, dt, dj, sj, spec, tmp, S12)
         plan.wct_coherence(S.ptr, S12.ptr, rows, n0, n0, P.ptr)     # result (reals) re-uses P's storage
+        if consume is not None:
+            consume(plan, P, rows, n0)
+            plan.sync()
+            return None, None
         wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64)
         awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64) if want_angle else None
         return wct_, awct
     finally:
-        sc.free()
+        if pool is None:
+            sc.free()
 
 
 def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, wavelet="morlet",
@@ -518,8 +536,20 @@ def _mc_setup(mother, dt, dj, s0, J):
 
 def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False):
     """Per-scale histograms (1000 bins on [0, 1)) of the coherence of `draws` AR(1) surrogate pairs, taken
-    outside the COI (wavelet.py:609-630, vectorised).  The coherence runs on the GPU."""
-    hist = np.zeros((sj.size, _MC_BINS))
+    outside the COI (wavelet.py:609-630).  Coherence AND histogram run on the GPU (`cwt_coherence_histogram`):
+    per draw only the two surrogate series go up, and the rows x 1000 counters come down once at the end."""
+    rows = sj.size
+    # the part of row s outside the COI is one interval (the COI is a triangle); rows >= maxscale are not counted
+    lo = np.zeros(rows, dtype=np.int64)
+    hi = np.zeros(rows, dtype=np.int64)
+    for s in range(maxscale):
+        idx = np.flatnonzero(outside[s])
+        if idx.size:
+            if idx[-1] - idx[0] + 1 != idx.size:
+                raise AssertionError("cone of influence mask is not one interval")
+            lo[s], hi[s] = idx[0], idx[-1] + 1
+    max_span = int((hi - lo).max()) if rows else 0
+    sc = _Scratch(device)
     it = range(draws)
     if progress:
         try:
@@ -527,13 +557,22 @@ def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, pre
             it = tqdm(it)
         except ImportError:
             pass
-    for _ in it:
-        r2, _ = _coherence_on_device(rednoise(N, al1, 1), rednoise(N, al2, 1), dt, dj, sj, mother, precision,
-                                     device, want_angle=False)
-        for s in range(maxscale):
-            v = np.floor(r2[s, outside[s]] * _MC_BINS).astype(int)
-            hist[s] += np.bincount(v[(v >= 0) & (v < _MC_BINS)], minlength=_MC_BINS)
-    return hist
+    try:
+        plan0 = _plan(_next_pow2(N), precision, device, rows)
+        lo_d, hi_d, hist_d = sc.new(rows * 8), sc.new(rows * 8), sc.new(rows * _MC_BINS * 8)
+        lo_d.upload(plan0, lo)
+        hi_d.upload(plan0, hi)
+        hist_d.upload(plan0, np.zeros((rows, _MC_BINS), dtype=np.uint64))
+
+        def count(plan, r2, nrows, n0):
+            plan.coherence_histogram(r2.ptr, n0, nrows, lo_d.ptr, hi_d.ptr, max_span, _MC_BINS, hist_d.ptr)
+
+        for _ in it:
+            _coherence_on_device(rednoise(N, al1, 1), rednoise(N, al2, 1), dt, dj, sj, mother, precision,
+                                 device, want_angle=False, consume=count, pool=sc)
+        return hist_d.download(plan0, (rows, _MC_BINS), np.uint64).astype(np.float64)
+    finally:
+        sc.free()
 
 
 def _mc_percentiles(hist, rows_with_data, maxscale, significance_level):

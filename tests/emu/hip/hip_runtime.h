@@ -65,6 +65,11 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
 
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+
 // ---- runtime API subset -------------------------------------------------
 typedef int hipError_t;
 typedef void* hipStream_t;

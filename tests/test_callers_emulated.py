@@ -100,3 +100,44 @@ def test_wct_significance_monte_carlo_small(emulated, tmp_path, monkeypatch):
     again = pycwt_amd.wct_significance(0.3, 0.5, **kw)          # served from the cache file
     np.testing.assert_allclose(again, sig, equal_nan=True)
     assert len(list(tmp_path.glob("wct_sig_*_Morlet.gz"))) == 1
+
+
+def _histogram_case(lib, precision):
+    """cwt_coherence_histogram against numpy on a matrix with NaNs, negatives and values >= 1."""
+    from pycwt_amd import _hip
+    rng = np.random.default_rng(11)
+    rows, n, nbins = 5, 3000, 1000
+    real = np.float64 if precision == 64 else np.float32
+    r2 = rng.random((rows, n)).astype(real)
+    r2[0, ::7] = np.nan
+    r2[1, ::5] = 1.0            # floor(1.0 * 1000) = 1000: skipped (the reference would raise IndexError)
+    r2[2, ::3] = -0.25
+    r2[3, 10] = real(0.999999)
+    lo = np.array([0, 100, 1499, 2999, 7], dtype=np.int64)
+    hi = np.array([n, 2900, 1500, 2999, 8], dtype=np.int64)     # full row, interior, 1 column, empty, 1 column
+    plan = _hip.Plan(4096, precision, max_rows=8, lib=lib)
+    bufs = [_hip.DeviceBuffer(b, lib=lib) for b in (r2.nbytes, lo.nbytes, hi.nbytes, rows * nbins * 8)]
+    try:
+        for b, a in zip(bufs, (r2, lo, hi, np.zeros((rows, nbins), dtype=np.uint64))):
+            b.upload(plan, a)
+        for _ in range(2):                                       # accumulates across calls
+            plan.coherence_histogram(bufs[0].ptr, n, rows, bufs[1].ptr, bufs[2].ptr, int((hi - lo).max()), nbins,
+                                     bufs[3].ptr)
+        got = bufs[3].download(plan, (rows, nbins), np.uint64)
+    finally:
+        for b in bufs:
+            b.free()
+        plan.close()
+    want = np.zeros((rows, nbins), dtype=np.uint64)
+    for s in range(rows):
+        with np.errstate(invalid="ignore"):
+            v = np.floor(r2[s, lo[s]:hi[s]] * real(nbins))
+        v = v[(v >= 0) & (v < nbins)].astype(int)
+        want[s] = 2 * np.bincount(v, minlength=nbins)
+    np.testing.assert_array_equal(got, want)
+    assert got[3].sum() == 0 and got[2].sum() == 2 and got[4].sum() == 2
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_coherence_histogram_matches_numpy(emu_library, precision):
+    _histogram_case(emu_library, precision)

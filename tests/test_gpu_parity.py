@@ -283,6 +283,12 @@ def test_wct_significance_gpu(hip_library, tmp_path, monkeypatch):
     assert sig[ok].max() - sig[ok].min() < 0.4
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+def test_coherence_histogram_gpu(hip_library, precision):
+    from test_callers_emulated import _histogram_case
+    _histogram_case(hip_library, precision)
+
+
 def test_custom_mother_objects_on_gpu(hip_library):
     """Duck-typed mothers go through the explicit filter-bank kernel (all three transform paths)."""
     import scipy.fft as sfft
