@@ -525,13 +525,23 @@ _MC_BINS = 1000
 
 
 def _mc_setup(mother, dt, dj, s0, J):
-    """Geometry of the Monte-Carlo surrogates (wavelet.py:591-606): series length 6*s_max/dt, scales, the
-    mask of points outside the cone of influence, and the last scale that has any."""
+    """Geometry of the Monte-Carlo surrogates (wavelet.py:591-606): series length 6*s_max/dt, scales, the part
+    of every row outside the cone of influence, and the last scale that has any.
+
+    The reference builds the rows x N mask `period <= coi` (1.5 GB at BASELINE config 5); the COI is a
+    symmetric triangle, so that mask is one interval [lo_j, hi_j) per row, found here by a binary search on
+    the rising half of `coi` with the same floating-point comparison."""
     N = int(np.ceil(s0 * (2 ** (J * dj)) / dt * 6))
     sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
-    outside = (mother.flambda() * sj)[:, None] <= _coi(mother, N, dt)[None, :]
-    rows_with_data = outside.any(axis=1)
-    return N, sj, outside, rows_with_data, find(rows_with_data)[-1]
+    coi = _coi(mother, N, dt)
+    half = (N + 1) // 2
+    lo = np.searchsorted(coi[:half], mother.flambda() * sj, side="left").astype(np.int64)
+    hi = N - lo
+    empty = lo >= half
+    lo[empty] = 0
+    hi[empty] = 0
+    rows_with_data = hi > lo
+    return N, sj, (lo, hi), rows_with_data, find(rows_with_data)[-1]
 
 
 def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False):
@@ -539,15 +549,9 @@ def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, pre
     outside the COI (wavelet.py:609-630).  Coherence AND histogram run on the GPU (`cwt_coherence_histogram`):
     per draw only the two surrogate series go up, and the rows x 1000 counters come down once at the end."""
     rows = sj.size
-    # the part of row s outside the COI is one interval (the COI is a triangle); rows >= maxscale are not counted
-    lo = np.zeros(rows, dtype=np.int64)
-    hi = np.zeros(rows, dtype=np.int64)
-    for s in range(maxscale):
-        idx = np.flatnonzero(outside[s])
-        if idx.size:
-            if idx[-1] - idx[0] + 1 != idx.size:
-                raise AssertionError("cone of influence mask is not one interval")
-            lo[s], hi[s] = idx[0], idx[-1] + 1
+    lo, hi = (np.array(v, dtype=np.int64) for v in outside)        # [lo_s, hi_s): row s outside the COI
+    lo[maxscale:] = 0                                               # rows >= maxscale are not counted (:625)
+    hi[maxscale:] = 0
     max_span = int((hi - lo).max()) if rows else 0
     sc = _Scratch(device)
     it = range(draws)
@@ -567,9 +571,20 @@ def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, pre
         def count(plan, r2, nrows, n0):
             plan.coherence_histogram(r2.ptr, n0, nrows, lo_d.ptr, hi_d.ptr, max_span, _MC_BINS, hist_d.ptr)
 
-        for _ in it:
-            _coherence_on_device(rednoise(N, al1, 1), rednoise(N, al2, 1), dt, dj, sj, mother, precision,
-                                 device, want_angle=False, consume=count, pool=sc)
+        # the next surrogate pair is drawn on a helper thread while the GPU works on the current one (one
+        # worker: the pairs still come from the global NumPy generator in the reference's order)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def pair():
+            return rednoise(N, al1, 1), rednoise(N, al2, 1)
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(pair) if draws > 0 else None
+            for i in it:
+                n1, n2 = nxt.result()
+                nxt = pool.submit(pair) if i + 1 < draws else None
+                _coherence_on_device(n1, n2, dt, dj, sj, mother, precision, device, want_angle=False,
+                                     consume=count, pool=sc)
         return hist_d.download(plan0, (rows, _MC_BINS), np.uint64).astype(np.float64)
     finally:
         sc.free()

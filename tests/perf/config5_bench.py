@@ -29,16 +29,18 @@ if "--mc" in sys.argv:
     t = time.perf_counter(); n1 = pc.rednoise(Nmc, 0.7, 1); n2 = pc.rednoise(Nmc, 0.6, 1)
     print(f"two surrogate series on the host: {time.perf_counter() - t:.2f} s")
     plan = wv._plan(wv._next_pow2(Nmc), 64, 0, sj.size)
+    plan.set_option("profile", 1); plan.timings()
+    wv._mc_histogram(1, 0.7, 0.6, 1.0, 1 / 12, sj, Nmc, outside, maxscale, m, 64, 0)
+    tm = plan.timings(); plan.set_option("profile", 0)
+    print("GPU time of one draw by kernel class (ms):", {k: round(v[0], 1) for k, v in tm.items()}, "sum",
+          round(sum(v[0] for v in tm.values()), 1))
     times = []
-    for draws in (1, 4):
-        plan.set_option("profile", 1); plan.timings()
+    for draws in (2, 8):
         t = time.perf_counter()
         hist = wv._mc_histogram(draws, 0.7, 0.6, 1.0, 1 / 12, sj, Nmc, outside, maxscale, m, 64, 0)
         times.append(time.perf_counter() - t)
-        tm = plan.timings(); plan.set_option("profile", 0)
-    print("GPU time by kernel class, 4 draws (ms):", {k: round(v[0], 1) for k, v in tm.items()}, "sum",
-          round(sum(v[0] for v in tm.values()), 1))
-    per = (times[1] - times[0]) / 3
+    per = (times[1] - times[0]) / 6
     print(f"Monte-Carlo significance: series length {Nmc} (transform length 2^{int(np.ceil(np.log2(Nmc)))}), "
-          f"{hist.shape[0]} scales: first draw {times[0]:.2f} s (allocates the work matrices), then {per:.2f} s per "
-          f"draw; 300 draws = {300 * per:.0f} s on one GPU, {38 * per:.0f} s per rank on 8")
+          f"{hist.shape[0]} scales: 2 draws {times[0]:.2f} s, 8 draws {times[1]:.2f} s -> {per:.2f} s per "
+          f"draw + {times[0] - 2 * per:.1f} s once (work matrices); 300 draws = {300 * per:.0f} s on one GPU, "
+          f"{38 * per:.0f} s per rank on 8")
