@@ -153,6 +153,11 @@ int cwt_filter_rows(cwt_plan* plan, const void* spec_dev, int64_t spec_ld, int m
 int cwt_boxcar_scales(cwt_plan* plan, const void* in_dev, int nrows, int64_t ld, int64_t ncols,
                       const double* win_host, int nwin, void* out_dev);
 
+/* Cross wavelet spectrum (pycwt/wavelet.py:399): out[j, n] = W1[j, n] * conj(W2[j, n]); nrows x ld complex of
+ * the plan's precision, n < ncols; out_dev may be W1_dev.                                            */
+int cwt_cross_spectrum(cwt_plan* plan, const void* W1_dev, const void* W2_dev, int nrows, int64_t ld,
+                       int64_t ncols, void* out_dev);
+
 /* Element-wise inputs of the coherence (wavelet.py:503-514), all nrows x ld:
  *   P = (|W1|^2 + i*|W2|^2)/s   (the two auto-spectra packed into one complex matrix: the smoothing
  *                                kernel is real, so one smoothing pass serves both)

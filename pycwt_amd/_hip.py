@@ -42,6 +42,7 @@ SYMBOLS = [
     ("cwt_filter_rows", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
     ("cwt_boxcar_scales", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int, _P]),
+    ("cwt_cross_spectrum", C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int64, _P]),
     ("cwt_wct_products", C.c_int, [_P, _P, _P, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_int64, _P, _P, _P]),
     ("cwt_wct_coherence", C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int64, _P]),
     ("cwt_icwt_reduce", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double),
@@ -205,6 +206,9 @@ class Plan:
 
     def time_mean_power(self, W_dev: int, ldw: int, ncols: int, nrows: int, out_dev: int):
         self.lib.check(self.lib.cwt_time_mean_power(self.h, _P(W_dev), ldw, ncols, nrows, _P(out_dev)))
+
+    def cross_spectrum(self, W1_dev: int, W2_dev: int, nrows: int, ld: int, ncols: int, out_dev: int):
+        self.lib.check(self.lib.cwt_cross_spectrum(self.h, _P(W1_dev), _P(W2_dev), nrows, ld, ncols, _P(out_dev)))
 
     def coherence_histogram(self, r2_dev: int, ld: int, nrows: int, lo_dev: int, hi_dev: int, max_span: int,
                             nbins: int, hist_dev: int):

@@ -1061,6 +1061,22 @@ int cwt_wct_products(cwt_plan* p, const void* W1_dev, const void* W2_dev, const 
                        : wct_products_impl<float>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev);
 }
 
+int cwt_cross_spectrum(cwt_plan* p, const void* W1_dev, const void* W2_dev, int nrows, int64_t ld, int64_t ncols,
+                       void* out_dev) {
+  if (!p || !W1_dev || !W2_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1 || nrows > 65535 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
+  HIPCHECK(hipSetDevice(p->device));
+  const dim3 grid(unsigned((ncols + 255) / 256), unsigned(nrows));
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    if (p->prec == 64)
+      hipLaunchKernelGGL((k_cross_spectrum<double>), grid, dim3(256), 0, p->stream, static_cast<const double2*>(W1_dev),
+                         static_cast<const double2*>(W2_dev), long(ld), long(ncols), static_cast<double2*>(out_dev));
+    else
+      hipLaunchKernelGGL((k_cross_spectrum<float>), grid, dim3(256), 0, p->stream, static_cast<const float2*>(W1_dev),
+                         static_cast<const float2*>(W2_dev), long(ld), long(ncols), static_cast<float2*>(out_dev));
+  });
+}
+
 int cwt_boxcar_scales(cwt_plan* p, const void* in_dev, int nrows, int64_t ld, int64_t ncols, const double* win,
                       int nwin, void* out_dev) {
   if (!p || !in_dev || !win || !out_dev) return fail(CWT_EINVAL, "NULL argument");

@@ -821,6 +821,18 @@ __global__ void k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int 
   out[n] = coeff * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
+// Cross wavelet spectrum W12 = W1 conj(W2) (pycwt/wavelet.py:399).  `out` may be W1 (every thread reads its own
+// element of both inputs before it writes).
+template <typename T>
+__global__ void k_cross_spectrum(const cplx<T>* W1, const cplx<T>* __restrict__ W2, long ld, long ncols,
+                                 cplx<T>* out) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  const long i = long(blockIdx.y) * ld + n;
+  const cplx<T> a = W1[i], b = W2[i];
+  out[i] = mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
 // Monte-Carlo significance of the coherence (pycwt/wavelet.py:609-630): per-scale histogram of floor(R2 * nbins)
 // over the columns [lo_j, hi_j) that lie outside the cone of influence; values outside [0, nbins) and NaNs are
 // skipped.  One LDS histogram per workgroup, merged into the global one (accumulated over the draws).

@@ -46,10 +46,12 @@ def _plan(nfft: int, precision: int, device: int, rows: int) -> _hip.Plan:
     return plan
 
 
-def _device_id(mother):
+def _device_id(mother, strict=True):
     try:
         return mother.device_id()
     except AttributeError:
+        if not strict:
+            return None
         raise NotImplementedError(
             "pycwt_amd.cwt needs a built-in mother (Morlet, Paul, DOG, MexicanHat from pycwt_amd); "
             f"got {type(mother).__name__} without device_id()") from None
@@ -200,7 +202,7 @@ class DeviceTransform:
             out.free()
 
     def W(self):
-        return self._buf.download(self._plan, self.shape, self._plan.cplx).astype(np.complex128)
+        return self._buf.download(self._plan, self.shape, self._plan.cplx).astype(np.complex128, copy=False)
 
     def global_power(self):
         """mean over time of |W|^2 per scale (`power.mean(axis=1)`, sample/simple_sample.py:79)."""
@@ -401,9 +403,23 @@ def xwt(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wavelet="mo
     y1, y2 = np.asarray(y1), np.asarray(y2)
     std1, std2 = (1., 1.) if normalize else (y1.std(), y2.std())
     kw = dict(dj=dj, s0=s0, J=J, wavelet=mother, precision=precision, device=device)
-    W1, sj, freq, coi, _, _ = cwt(_normalised(y1, normalize), dt, **kw)
-    W2, sj, freq, coi, _, _ = cwt(_normalised(y2, normalize), dt, **kw)
-    W12 = W1 * W2.conj()
+    if _device_id(mother, strict=False) is not None and len(y1) == len(y2):
+        # both transforms and the product stay on the device; one matrix crosses PCIe instead of two
+        T1 = cwt_device(_normalised(y1, normalize), dt, **kw)
+        try:
+            T2 = cwt_device(_normalised(y2, normalize), dt, **kw)
+            try:
+                rows, n0 = T1.shape
+                T1._plan.cross_spectrum(T1.device_ptr, T2.device_ptr, rows, n0, n0, T1.device_ptr)
+                W12, freq, coi = T1.W(), T1.freqs, T1.coi
+            finally:
+                T2.close()
+        finally:
+            T1.close()
+    else:
+        W1, sj, freq, coi, _, _ = cwt(_normalised(y1, normalize), dt, **kw)
+        W2, sj, freq, coi, _, _ = cwt(_normalised(y2, normalize), dt, **kw)
+        W12 = W1 * W2.conj()
     a1, a2 = ar1(y1)[0], ar1(y2)[0]
     pk = np.sqrt(ar1_spectrum(freq * dt, a1) * ar1_spectrum(freq * dt, a2))
     dof = mother.dofmin
@@ -480,8 +496,8 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
             consume(plan, P, rows, n0)
             plan.sync()
             return None, None
-        wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64)
-        awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64) if want_angle else None
+        wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False)
+        awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False) if want_angle else None
         return wct_, awct
     finally:
         if pool is None:

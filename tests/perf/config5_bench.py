@@ -12,15 +12,18 @@ N = 1 << 20
 rng = np.random.default_rng(5)
 y1 = pc.rednoise(N, 0.7, 1) if hasattr(pc, "rednoise") else rng.standard_normal(N)
 y2 = 0.5 * y1 + rng.standard_normal(N)
-for rep in range(2):
-    t = time.perf_counter()
-    WCT, aWCT, coi, freq, sig = pc.wct(y1, y2, 1.0, sig=False)
-    el = time.perf_counter() - t
-print(f"wct N=2^20: {WCT.shape[0]} scales, {el*1e3:.0f} ms end to end (host in, two {WCT.nbytes/2**30:.1f} GiB result "
-      f"matrices out over PCIe); coherence in [{np.nanmin(WCT):.3f}, {np.nanmax(WCT):.3f}]")
-t = time.perf_counter()
-Wx, coi, freq, signif = pc.xwt(y1, y2, 1.0)[:4]
-print(f"xwt N=2^20: {Wx.shape[0]} scales, {(time.perf_counter() - t)*1e3:.0f} ms end to end "
+def best_of(f, reps=4):
+    out, times = None, []
+    for _ in range(reps):
+        t = time.perf_counter(); out = f(); times.append(time.perf_counter() - t)
+    return out, min(times), max(times)
+
+(WCT, aWCT, coi, freq, sig), lo, hi = best_of(lambda: pc.wct(y1, y2, 1.0, sig=False))
+print(f"wct N=2^20: {WCT.shape[0]} scales, {lo*1e3:.0f}-{hi*1e3:.0f} ms end to end over 4 calls (host in, two "
+      f"{WCT.nbytes/2**30:.1f} GiB result matrices out over PCIe into fresh NumPy arrays); coherence in "
+      f"[{np.nanmin(WCT):.3f}, {np.nanmax(WCT):.3f}]")
+(Wx, coi, freq, signif), lo, hi = best_of(lambda: pc.xwt(y1, y2, 1.0))
+print(f"xwt N=2^20: {Wx.shape[0]} scales, {lo*1e3:.0f}-{hi*1e3:.0f} ms end to end over 4 calls "
       f"({Wx.nbytes/2**30:.1f} GiB complex result over PCIe)")
 if "--mc" in sys.argv:
     m = pc.Morlet(6)
