@@ -1034,6 +1034,15 @@ int boxcar_impl(cwt_plan* p, const void* in, int nrows, int64_t ld, int64_t ncol
                 void* out) {
   int rc = upload_reals<T>(p, win, nwin);
   if (rc) return rc;
+  const size_t ring_bytes = size_t(nwin) * 256 * sizeof(cplx<T>);
+  if (nwin > 1 && ring_bytes <= 64 * 1024) {       // sliding window over 32-row strips (see the kernel)
+    const int RB = 32;
+    return timed_launch(p, KC_ELEMENTWISE, [&] {
+      hipLaunchKernelGGL((k_boxcar_scales_ring<T>), dim3(unsigned((ncols + 255) / 256), unsigned((nrows + RB - 1) / RB)),
+                         dim3(256), ring_bytes, p->stream, static_cast<const cplx<T>*>(in), nrows, long(ld),
+                         long(ncols), static_cast<const T*>(p->weights_dev), nwin, static_cast<cplx<T>*>(out), RB);
+    });
+  }
   return timed_launch(p, KC_ELEMENTWISE, [&] {
     hipLaunchKernelGGL((k_boxcar_scales<T>), dim3(unsigned((ncols + 255) / 256), nrows), dim3(256), 0, p->stream,
                        static_cast<const cplx<T>*>(in), nrows, long(ld), long(ncols),

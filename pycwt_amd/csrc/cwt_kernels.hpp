@@ -785,6 +785,37 @@ __global__ void k_boxcar_scales(const cplx<T>* __restrict__ in, int nrows, long 
   out[long(j) * ld + n] = mk<T>(sr, si);
 }
 
+// Same sums (same order), but every workgroup walks RB consecutive rows of its 256 columns and keeps the last L
+// input rows in a per-thread ring in LDS: every input element is read from memory (RB + L - 1) / RB times
+// instead of L times (L = 14 rows for the default dj = 1/12: 332 GB -> 34 GB per smoothing at BASELINE config 5).
+template <typename T>
+__global__ void k_boxcar_scales_ring(const cplx<T>* __restrict__ in, int nrows, long ld, long ncols,
+                                     const T* __restrict__ win, int L, cplx<T>* __restrict__ out, int RB) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  cplx<T>* ring = reinterpret_cast<cplx<T>*>(lds_raw) + threadIdx.x;       // slot s at ring[s * blockDim.x]
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = n < ncols;
+  const int j0 = blockIdx.y * RB, c = (L - 1) / 2, jend = (j0 + RB < nrows) ? j0 + RB : nrows;
+  const int bias = L * (nrows / L + 2);                                     // keeps (jj + bias) positive
+  auto fetch = [&](int jj) {
+    return (live && jj >= 0 && jj < nrows) ? in[long(jj) * ld + n] : mk<T>(T(0), T(0));
+  };
+  for (int jj = j0 + c - L + 1; jj < j0 + c; ++jj) ring[((jj + bias) % L) * blockDim.x] = fetch(jj);
+  for (int j = j0; j < jend; ++j) {
+    ring[((j + c + bias) % L) * blockDim.x] = fetch(j + c);
+    T sr = 0, si = 0;
+    for (int i = 0; i < L; ++i) {
+      const int jj = j + c - i;
+      if (jj >= 0 && jj < nrows) {
+        const cplx<T> v = ring[((jj + bias) % L) * blockDim.x];
+        sr += win[i] * v.x;
+        si += win[i] * v.y;
+      }
+    }
+    if (live) out[long(j) * ld + n] = mk<T>(sr, si);
+  }
+}
+
 // WCT = |S12|^2 / (S1 S2) with S = S1 + i S2
 template <typename T>
 __global__ void k_wct_coherence(const cplx<T>* __restrict__ S, const cplx<T>* __restrict__ S12, long ld,

@@ -141,3 +141,31 @@ def _histogram_case(lib, precision):
 @pytest.mark.parametrize("precision", [64, 32])
 def test_coherence_histogram_matches_numpy(emu_library, precision):
     _histogram_case(emu_library, precision)
+
+
+def _boxcar_case(lib, precision):
+    """cwt_boxcar_scales == scipy.signal.convolve2d(T, win[:, None], 'same') for window lengths on both sides of
+    the sliding-window kernel's limit, rows not a multiple of its strip height, ragged column count."""
+    from scipy.signal import convolve2d
+    from pycwt_amd import _hip
+    rng = np.random.default_rng(4)
+    rows, n = 70, 300
+    cplx = np.complex128 if precision == 64 else np.complex64
+    T = (rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))).astype(cplx)
+    plan = _hip.Plan(512, precision, max_rows=128, lib=lib)
+    a, b = _hip.DeviceBuffer(T.nbytes, lib=lib), _hip.DeviceBuffer(T.nbytes, lib=lib)
+    try:
+        a.upload(plan, T)
+        for L in (1, 2, 3, 14, 16, 17, 33, 70):
+            win = rng.random(L)
+            plan.boxcar_scales(a.ptr, rows, n, n, win, b.ptr)
+            got = b.download(plan, (rows, n), cplx)
+            want = convolve2d(T.astype(np.complex128), win[:, None], "same")
+            np.testing.assert_allclose(got, want, rtol=0, atol=(1e-12 if precision == 64 else 2e-5) * L)
+    finally:
+        a.free(); b.free(); plan.close()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_boxcar_matches_convolve2d(emu_library, precision):
+    _boxcar_case(emu_library, precision)

@@ -289,6 +289,12 @@ def test_coherence_histogram_gpu(hip_library, precision):
     _histogram_case(hip_library, precision)
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+def test_boxcar_gpu(hip_library, precision):
+    from test_callers_emulated import _boxcar_case
+    _boxcar_case(hip_library, precision)
+
+
 def test_custom_mother_objects_on_gpu(hip_library):
     """Duck-typed mothers go through the explicit filter-bank kernel (all three transform paths)."""
     import scipy.fft as sfft
