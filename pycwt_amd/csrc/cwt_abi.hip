@@ -69,6 +69,7 @@ struct cwt_plan {
   int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
   int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
+  int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
   int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain (measured: +2 % in
                            // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
@@ -445,10 +446,31 @@ void launch_narrow_ct_big(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   }
 }
 
+// Large transforms (N >= 2^23, complex128): a 4096-point column FFT leaves only 2 columns per 8192-point tile, i.e.
+// 32-byte memory segments in pass A.  16384-point tiles (1024 threads, 128 KiB of LDS, one workgroup per CU)
+// double them: pass A -33 %, forward FFT's pass A -63 % at N = 2^23.  (Pass B measured slower on such tiles.)
+template <typename F>
+void allow_big_lds(F kernel) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          144 * 1024) != hipSuccess)
+    (void)hipGetLastError();
+}
+
 template <typename T, int LOGR, int MODE>
 void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo, long n0,
                       long in_ld, cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
+  if constexpr (sizeof(T) == 8 && LOGR == 12) {
+    if (p->big_tiles) {
+      constexpr int LP = 14;
+      static const bool once = (allow_big_lds(&k_pass_a_ct<T, LOGR, LP, MODE>), true);
+      (void)once;
+      hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LP, MODE>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
+                         (size_t(1) << LP) * sizeof(T), st, in, rows, mo, tw_table<T>(p, LOGR), twn_of<T>(p),
+                         p->logN, n0, in_ld, Z);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LOGP, MODE>), dim3(1u << (p->logN - LOGP), cnt),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), st, in, rows, mo,
                      tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
@@ -461,6 +483,17 @@ void launch_pass_a_ct_rows(cwt_plan* p, const void* in, const RowDesc* rows, int
   if constexpr (LOGR <= 10) {
     if (p->pass_a_small) {
       constexpr int LP = LOGP - 1;
+      hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
+                         (size_t(1) << LP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
+                         static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+      return;
+    }
+  }
+  if constexpr (sizeof(T) == 8 && LOGR == 12) {
+    if (p->big_tiles) {
+      constexpr int LP = 14;
+      static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP>), true);
+      (void)once;
       hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
                          (size_t(1) << LP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
                          static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
@@ -819,6 +852,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
+  else if (k == "big_tiles") p->big_tiles = value != 0;
   else if (k == "narrow_small") p->narrow_small = value != 0;
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
