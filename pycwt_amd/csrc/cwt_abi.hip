@@ -70,6 +70,7 @@ struct cwt_plan {
   int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
+  int force_logk = 0;
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
   int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain (measured: +2 % in
                            // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
@@ -357,6 +358,7 @@ int chunk_rows_of(const cwt_plan* p) {
 int two_pass_logk(const cwt_plan* p) {
   int lk = std::min(10, p->logN - 4);
   if (p->logN >= 22) lk = 11;
+  if (p->force_logk) lk = p->force_logk;
   lk = std::max(lk, p->logN - p->loglmax);
   lk = std::min(lk, p->loglmax);
   return lk;
@@ -852,6 +854,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
+  else if (k == "two_pass_logk") p->force_logk = int(value);
   else if (k == "big_tiles") p->big_tiles = value != 0;
   else if (k == "narrow_small") p->narrow_small = value != 0;
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
