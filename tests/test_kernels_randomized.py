@@ -38,6 +38,8 @@ def cases(draw):
         opts["narrow_terms"] = draw(st.integers(1, 4))
         opts["band_pass_a"] = draw(st.integers(0, 1))
         opts["narrow_big"] = draw(st.integers(0, 1))
+        opts["pass_a_small"] = draw(st.integers(0, 1))
+        opts["narrow_small"] = draw(st.integers(0, 1))
     return N, n0, kind, param, np.array([2.0 ** e for e in expo]), prec, opts, draw(st.integers(0, 2 ** 31))
 
 
