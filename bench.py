@@ -88,6 +88,12 @@ def main():
                     help="initialise the process group and run the collectives even with one rank (smoke test of the RCCL path)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result.  Libraries that write to the C stdout stream (RCCL prints
+    # a version banner there on its first collective) are sent to stderr for the duration of the run.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from pycwt_amd import _hip
@@ -240,11 +246,19 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(x_host, dt, kind, param, sj_all)
-    if rank == 0:
-        print(json.dumps(out))
     plan.close()
     if use_dist:
         dist.destroy_process_group()
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)           # drain what C libraries buffered while fd 1 pointed at stderr
+    except OSError:
+        pass
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
