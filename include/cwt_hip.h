@@ -79,6 +79,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "pass_a_small" 0 = pass A on full-size workgroup tiles (default 1: half-size tiles, 4 per CU)
  *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size)
  *   "two_pass_logk" log2 of the row length K of the two-pass split N = R*K (0 = default: 1024 up to 2^21, 2048 above)
+ *   "pass_b_small" 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
+ *   "stamps"       n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
@@ -213,6 +215,12 @@ int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother,
  * in *n and resets the accumulators.  Synchronises the stream.              */
 int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_ms,
                      int* launches, int* n);
+/* Diagnostics: with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
+ * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
+ * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in
+ * issue order, until n records are used.  Copies up to cap_records records to out_host, returns the number recorded
+ * since the last call in *n_records and starts over.  Synchronises the stream.                                       */
+int cwt_plan_read_stamps(cwt_plan* plan, uint64_t* out_host, int64_t cap_records, int64_t* n_records);
 /* How the last cwt_transform_rows call split its rows: counts[0] = rows done by the single-workgroup
  * kernel, [1] = band-limited single pass with K <= 1024, [2] = two-pass, [3] = band-limited single pass
  * with K = 2048 (fp64, 16384-point workgroups). */

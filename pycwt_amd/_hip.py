@@ -55,6 +55,7 @@ SYMBOLS = [
                                    C.POINTER(C.c_double), C.c_int, _P, _P]),
     ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
 ]
 
@@ -235,6 +236,13 @@ class Plan:
         n = C.c_int(0)
         self.lib.check(self.lib.cwt_plan_timings(self.h, cap, names, ms, cnt, C.byref(n)))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n.value, cap))}
+
+    def read_stamps(self, cap: int):
+        """(n_recorded, records[min(n, cap), 8] uint64) of the phase stamps since the last call (option "stamps")."""
+        out = np.zeros((cap, 8), dtype=np.uint64)
+        n = C.c_int64(0)
+        self.lib.check(self.lib.cwt_plan_read_stamps(self.h, out.ctypes.data_as(_P), cap, C.byref(n)))
+        return n.value, out[:min(n.value, cap)]
 
     def last_split(self):
         c = (C.c_int * 4)()

@@ -76,6 +76,10 @@ struct cwt_plan {
                            // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
+  int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
+  // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
+  unsigned long long* stamps = nullptr;
+  int64_t stamp_cap = 0, stamp_next = 0;
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
@@ -478,33 +482,47 @@ void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt,
                      tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
 }
 
+// Stamp records of one launch of `blocks` workgroups (base == nullptr: none left or stamping is off).
+Stamps take_stamps(cwt_plan* p, int64_t blocks) {
+  Stamps st{nullptr, 0u};
+  if (p->stamps && p->stamp_next + blocks <= p->stamp_cap) {
+    st.base = p->stamps;
+    st.first = unsigned(p->stamp_next);
+    p->stamp_next += blocks;
+  }
+  return st;
+}
+
+template <typename T, int LOGR, int LP>
+void launch_pass_a_ct_rows_lp(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
+                              cplx<T>* Z, hipStream_t st) {
+  const dim3 grid(1u << (p->logN - LP), cnt), block(1 << (LP - 4));
+  const size_t lds = (size_t(1) << LP) * sizeof(T);
+  const Stamps sp = take_stamps(p, int64_t(grid.x) * grid.y);
+  if constexpr (LP == 14) {
+    static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, false>),
+                              allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, true>), true);
+    (void)once;
+  }
+  if (sp.base)
+    hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, true>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
+                       rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
+  else
+    hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, false>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
+                       rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
+}
+
 template <typename T, int LOGR>
 void launch_pass_a_ct_rows(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
                            cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
   if constexpr (LOGR <= 10) {
-    if (p->pass_a_small) {
-      constexpr int LP = LOGP - 1;
-      hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
-                         (size_t(1) << LP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
-                         static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
-      return;
-    }
+    if (p->pass_a_small) return launch_pass_a_ct_rows_lp<T, LOGR, LOGP - 1>(p, in, rows, cnt, mo, Z, st);
   }
   if constexpr (sizeof(T) == 8 && LOGR == 12) {
-    if (p->big_tiles) {
-      constexpr int LP = 14;
-      static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP>), true);
-      (void)once;
-      hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
-                         (size_t(1) << LP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
-                         static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
-      return;
-    }
+    if (p->big_tiles) return launch_pass_a_ct_rows_lp<T, LOGR, 14>(p, in, rows, cnt, mo, Z, st);
   }
-  hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LOGP>), dim3(1u << (p->logN - LOGP), cnt), dim3(1 << (LOGP - 4)),
-                     (size_t(1) << LOGP) * sizeof(T), st, static_cast<const cplx<T>*>(in), rows, mo,
-                     static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
+  launch_pass_a_ct_rows_lp<T, LOGR, LOGP>(p, in, rows, cnt, mo, Z, st);
 }
 
 // Compile-time pass A for every column length R = 2^4 .. 2^12 (i.e. every N the two-pass path handles).
@@ -524,14 +542,32 @@ bool try_pass_a_ct(cwt_plan* p, int logR, const void* in, const RowDesc* rows, i
 #undef CWT_CASE
 }
 
+template <typename T, int LOGK, int LP, bool CONJ>
+void launch_pass_b_ct_lp(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
+                         const cplx<T>* Z, hipStream_t st) {
+  const size_t lds = ((size_t(1) << LP) + (size_t(1) << (LP - 4))) * sizeof(T);
+  const dim3 grid(1u << (p->logN - LP), cnt), block(1 << (LP - 4));
+  const Stamps sp = CONJ ? Stamps{nullptr, 0u} : take_stamps(p, int64_t(grid.x) * grid.y);
+  if constexpr (!CONJ) {
+    if (sp.base) {
+      hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, true>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
+                         p->logN, W, long(ldw), long(ncols), sp);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, false>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
+                     p->logN, W, long(ldw), long(ncols), sp);
+}
+
 template <typename T, int LOGK, bool CONJ>
 void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
                       const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
-  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-  hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LOGP, CONJ>), dim3(1u << (p->logN - LOGP), cnt),
-                     dim3(1 << (LOGP - 4)), lds, st, Z, rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw),
-                     long(ncols));
+  // half-size tiles keep the store segments >= 128 B only while TB = 2^(LOGP - 1 - LOGK) >= 128 B / sizeof(complex)
+  if constexpr (!CONJ && LOGP - 1 - LOGK >= (sizeof(T) == 8 ? 3 : 4)) {
+    if (p->pass_b_small) return launch_pass_b_ct_lp<T, LOGK, LOGP - 1, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
+  }
+  launch_pass_b_ct_lp<T, LOGK, LOGP, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
 }
 
 // Compile-time pass B for row lengths K = 2^9 .. 2^12 (K = 1024 for every N from 2^14 to 2^22).
@@ -818,7 +854,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW};
+  void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (p->rows_pinned) (void)hipHostFree(p->rows_pinned);
   if (p->weights_pinned) (void)hipHostFree(p->weights_pinned);
@@ -858,6 +894,20 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "big_tiles") p->big_tiles = value != 0;
   else if (k == "narrow_small") p->narrow_small = value != 0;
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
+  else if (k == "pass_b_small") p->pass_b_small = value != 0;
+  else if (k == "stamps") {
+    if (value < 0 || value > (int64_t(1) << 24)) return fail(CWT_EINVAL, "stamps: record count in [0, 2^24]");
+    HIPCHECK(hipSetDevice(p->device));
+    HIPCHECK(hipStreamSynchronize(p->stream));
+    if (p->stamps) { HIPCHECK(hipFree(p->stamps)); p->stamps = nullptr; }
+    p->stamp_cap = p->stamp_next = 0;
+    if (value > 0) {
+      if (hipMalloc(reinterpret_cast<void**>(&p->stamps), size_t(value) * 64) != hipSuccess)
+        return fail(CWT_ENOMEM, "stamp buffer allocation failed");
+      HIPCHECK(hipMemset(p->stamps, 0, size_t(value) * 64));
+      p->stamp_cap = value;
+    }
+  }
   else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);
@@ -1269,6 +1319,17 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
     ++k;
   }
   *n = k;
+  return CWT_OK;
+}
+
+int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, int64_t* n_records) {
+  if (!p || !n_records) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(p->device));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  const int64_t n = std::min<int64_t>(p->stamp_next, cap_records < 0 ? 0 : cap_records);
+  if (n > 0 && out_host) HIPCHECK(hipMemcpy(out_host, p->stamps, size_t(n) * 64, hipMemcpyDeviceToHost));
+  *n_records = p->stamp_next;
+  p->stamp_next = 0;
   return CWT_OK;
 }
 

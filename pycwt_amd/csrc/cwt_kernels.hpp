@@ -20,6 +20,27 @@
 #ifndef CWT_MAX_THREADS
 #define CWT_MAX_THREADS 1024
 #endif
+// Minimum resident waves per SIMD the compiler must allow for (second __launch_bounds__ argument, i.e. the VGPR
+// budget: 4 -> 128, 5 -> 96, 6 -> 80, 8 -> 64 registers) of the compile-time kernels, per precision.  Measured
+// defaults; override with -D for tuning runs.
+#ifndef CWT_LB_NARROW_F64
+#define CWT_LB_NARROW_F64 4
+#endif
+#ifndef CWT_LB_NARROW_F32
+#define CWT_LB_NARROW_F32 4
+#endif
+#ifndef CWT_LB_PASS_A_F64
+#define CWT_LB_PASS_A_F64 4
+#endif
+#ifndef CWT_LB_PASS_A_F32
+#define CWT_LB_PASS_A_F32 4
+#endif
+#ifndef CWT_LB_PASS_B_F64
+#define CWT_LB_PASS_B_F64 4
+#endif
+#ifndef CWT_LB_PASS_B_F32
+#define CWT_LB_PASS_B_F32 8
+#endif
 namespace cwt {
 
 enum : int { MOTHER_MORLET = 0, MOTHER_PAUL = 1, MOTHER_DOG = 2, MOTHER_TABLE = 3 };
@@ -125,6 +146,31 @@ __device__ __forceinline__ cplx<T> filtered_bin(const cplx<T>* __restrict__ xhat
 }
 
 __device__ __forceinline__ int signed_bin(int k, int N) { return k < (N >> 1) ? k : k - N; }
+
+// Phase stamps (diagnostics only, plan option "stamps"; the STAMP = false instantiations carry none of this):
+// thread 0 of a workgroup records the 100 MHz wall clock at up to 6 points of its life (slot s of its 8-word
+// record), its placement (HW_ID | XCC_ID << 32) in word 6 and its block ids in word 7.  `drain` waits for
+// every outstanding memory operation of the calling wave first, so that the stamp marks data arrival /
+// write acknowledgement rather than instruction issue.
+struct Stamps {
+  unsigned long long* base;
+  unsigned first;             // record index of workgroup (0, 0) of this launch
+};
+template <bool STAMP>
+__device__ __forceinline__ void stamp(const Stamps& st, int slot, bool drain) {
+  if constexpr (STAMP) {
+    if (drain) __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) {
+      unsigned long long* rec = st.base + 8ull * (st.first + blockIdx.y * gridDim.x + blockIdx.x);
+      rec[slot] = wall_clock64();
+      if (slot == 0) {
+        rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        rec[7] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 32);
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_small: whole transform of length N = 2^logN (16..lmax) inside one workgroup, TB rows per WG.
@@ -513,7 +559,7 @@ __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat,
 // class), every workgroup branches once to the body specialised for its row's (K, terms).  One
 // launch instead of one per class removes ~10 kernel boundaries and partial last waves per transform.
 template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
 k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
                 long ncols) {
@@ -555,7 +601,7 @@ k_narrow_ct_big(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 }
 
 template <typename T, int LOGR, int LOGP, int MODE>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_A_F64 : CWT_LB_PASS_A_F32))
 k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother mo,
             const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, long n0, long in_ld,
             cplx<T>* __restrict__ Z) {
@@ -674,20 +720,33 @@ __device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xha
 
 // Pass A of a chunk of wide rows: every workgroup branches once on its row's class (rd.logK: 0 = all
 // R inputs may be non-zero -> full column FFT; 4/6/8 -> support spans <= 16/64/256 bins k1).
-template <typename T, int LOGR, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+template <typename T, int LOGR, int LOGP, bool STAMP = false>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_A_F64 : CWT_LB_PASS_A_F32))
 k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
-                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ Z) {
+                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ Z, Stamps st) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
+  stamp<STAMP>(st, 0, false);
   const RowDesc rd = rows[blockIdx.y];
   cplx<T>* z = Z + (long(blockIdx.y) << logN);
   if constexpr (LOGR > 4)
-    if (rd.logK == 4) { pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+    if (rd.logK == 4) {
+      pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds);
+      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
+      return;
+    }
   if constexpr (LOGR > 6)
-    if (rd.logK == 6) { pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+    if (rd.logK == 6) {
+      pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds);
+      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
+      return;
+    }
   if constexpr (LOGR > 8)
-    if (rd.logK == 8) { pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds); return; }
+    if (rd.logK == 8) {
+      pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds);
+      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
+      return;
+    }
   // full column FFT (same code as k_pass_a_ct<..., IN_SPECTRUM>)
   constexpr int LOGTQ = LOGP - LOGR, LOGNT = LOGR - 4, NT = 1 << LOGNT;
   using F = ct::Fft<T, LOGR, LOGTQ, true>;
@@ -704,7 +763,9 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
     const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
     re[e] = v.x; im[e] = v.y;
   }
+  stamp<STAMP>(st, 1, true);
   f.run(re, im, lds, tw_all + ((1 << LOGR) - 2));
+  stamp<STAMP>(st, 2, false);
   const unsigned off = (unsigned(f.j) << logK) + q;
   cplx<T> cur = twn(q * unsigned(f.j));
   const cplx<T> step = twn(q << LOGNT);
@@ -714,17 +775,20 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
         mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
     cur = cmul<T>(cur, step);
   }
+  stamp<STAMP>(st, 3, false);
+  stamp<STAMP>(st, 4, true);
 }
 
-template <typename T, int LOGK, int LOGP, bool CONJ>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 4 : 8))
+template <typename T, int LOGK, int LOGP, bool CONJ, bool STAMP = false>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_B_F64 : CWT_LB_PASS_B_F32))
 k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-            const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+            const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols, Stamps st) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, BD = 1 << (LOGP - 4);
   using F = ct::Fft<T, LOGK, LOGTB, false>;
   const int logR = logN - LOGK;
+  stamp<STAMP>(st, 0, false);
   F f;
   f.j = threadIdx.x & (NT - 1);
   f.t = threadIdx.x >> LOGNT;
@@ -737,10 +801,14 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const cplx<T> v = (z + e * NT)[zoff];
     re[e] = v.x; im[e] = v.y;
   }
+  stamp<STAMP>(st, 1, true);
   f.run(re, im, lds, tw);
+  stamp<STAMP>(st, 2, false);
 
   const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
   transpose_store<T, LOGK, LOGP, CONJ>(re, im, lds, f.t, f.j, W + orow * ldw, logR, r0, ncols);
+  stamp<STAMP>(st, 3, false);
+  stamp<STAMP>(st, 4, true);
 }
 
 // ---------------------------------------------------------------------------------------------

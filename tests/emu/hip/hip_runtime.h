@@ -59,6 +59,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 // round-robin yield is a (stronger) stand-in
 #define __builtin_amdgcn_wave_barrier() hipemu::barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+#define __builtin_amdgcn_s_getreg(imm) (0u)
+static inline unsigned long long wall_clock64() { return 0ull; }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __expf(x) expf(x)
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::cur->smem);
@@ -94,6 +97,7 @@ static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }

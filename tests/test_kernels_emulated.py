@@ -177,3 +177,35 @@ def test_k2048_single_pass_rows(emu_library, kind, param):
         per_row, _ = row_errors(W, ref)
         assert per_row.max() < 1e-12, (big, per_row)
     assert splits[1]["narrow"] > splits[0]["narrow"]
+
+
+@pytest.mark.parametrize("opts", [{"two_pass_logk": 9, "pass_b_small": 1}, {"pass_b_small": 1}])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_two_pass_layout_and_tile_options(emu_library, opts, prec):
+    """Half-size pass-B tiles (K = 512 x 8 residues) give the same rows as the default tiles (all pass-A classes)."""
+    N = 1 << (17 if opts.get("two_pass_logk") else 16)
+    x = np.random.default_rng(11).standard_normal(N - 1)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = 2.9 * N / np.array([60000.0, 30000.0, 20000.0, 9000.0, 2500.0])
+    o = dict(opts, narrow_big=0, narrow_terms=1)
+    plan = _hip.Plan(N, prec, max_rows=8, lib=emu_library, options=o)
+    W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
+    assert plan.last_split()["two_pass"] >= 4
+    plan.close()
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m)[:, :x.size])
+    assert per_row.max() < TOL[prec], (opts, per_row)
+
+
+def test_phase_stamps_are_recorded_per_workgroup(emu_library):
+    N = 1 << 16
+    x = np.random.default_rng(11).standard_normal(N)
+    plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options={"stamps": 4096, "narrow_big": 0, "narrow_terms": 1})
+    W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, [3.0, 9.0], want_xhat=False)
+    n, rec = plan.read_stamps(4096)
+    # pass A: 2 rows x N/4096 half-size tiles, pass B: 2 rows x N/8192 tiles
+    assert n == 2 * (N >> 12) + 2 * (N >> 13) and rec.shape == (n, 8)
+    assert set(rec[:, 7] >> np.uint64(32)) == {0, 1}
+    plan.set_option("stamps", 0)
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, np.array([3.0, 9.0]), orc.Mother(orc.MORLET, 6)))
+    assert per_row.max() < 1e-12
+    plan.close()
