@@ -3,17 +3,26 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3_paul|c3_dog]
 
-One "step" = one pass of the hot path over one synthetic signal: (broadcast of the signal when
-N > 1) -> forward FFT -> all rows of W written device-resident.  Inputs are resident in HBM when the
-timed region starts.  Workload at 1 GPU = BASELINE.json configs[1]: N = 2^20 fp64 samples, Morlet(6),
-256 scales spanning s0 = 2dt/flambda .. N*dt.  With G GPUs (one process per GPU,
-launched by torch.distributed.run) the scale grid is refined to 256*G rows over the same span and
-row j goes to rank j mod G (weak scaling: 256 rows per GPU); rank 0 owns the signal and broadcasts
-it over RCCL each step; there is no other collective.
+One "step" = one pass of the hot path over one synthetic signal: (broadcast of the signal when N > 1) -> forward
+FFT -> all rows of W written device-resident.  Inputs are resident in HBM when the timed region starts.
 
-Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` (dominant kernel,
-HIP-event timed inside this process) and `cpu_baseline` (the oracle timed on this box's host cores on
-a bounded row sample).
+Workload at 1 GPU = BASELINE.json configs[1]: N = 2^20 fp64 samples, Morlet(6), 256 scales spanning
+s0 = 2dt/flambda .. N*dt.  With G GPUs (one process per GPU, launched by torch.distributed.run) the
+SAME 256 rows are split over the ranks, row j -> rank j mod G (STRONG scaling, the quantity north_star's ">= 6x at
+8 GPUs" is about); rank 0 owns the signal and broadcasts it over RCCL each step, the broadcast of step i+1
+travelling while step i computes; there is no other collective.  `--weak` (and the `weak_scaling` block of the
+default multi-GPU line) refines the grid to 256*G rows instead, 256 per GPU.
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  roofline      dominant kernel, HIP-event timed inside this process in a separate pass
+  parity        (1 GPU) every row of W of the timed workload against the CPU oracle: max per-row error, worst
+                row, worst row per kernel class
+  cpu_baseline  (1 GPU) the oracle timed on this box's host cores on the same rows (kind "port") and the whole
+                reference function incl. its NaN scan + copy on a 64-row subset (`reference_as_is`)
+  extra         (1 GPU, default config) BASELINE config 3 -- fp32 Paul(4) and DOG(2) -- measured the same way
+
+`--emulate --backend gloo` runs the whole script on CPU against the emulated kernel library (tests/emu) with a small
+transform: a rehearsal of the launch / environment / stdout contract, not a measurement.
 """
 import argparse
 import json
@@ -29,10 +38,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 CONFIGS = {
     # name: (mother id, param, precision, label)
-    "c2": (0, 6.0, 64, "N=2^20 fp64 Morlet(6) 256 scales"),
-    "c3_paul": (1, 4.0, 32, "N=2^20 fp32 Paul(4) 256 scales"),
-    "c3_dog": (2, 2.0, 32, "N=2^20 fp32 DOG(2) 256 scales"),
+    "c2": (0, 6.0, 64, "fp64 Morlet(6)"),
+    "c3_paul": (1, 4.0, 32, "fp32 Paul(4)"),
+    "c3_dog": (2, 2.0, 32, "fp32 DOG(2)"),
 }
+PARITY_TOL = {64: 1e-11, 32: 3e-5}      # per-row max|dW|/max|W|; north_star: 1e-6 / 1e-3
 
 
 def scale_grid(N, dt, flambda, rows):
@@ -49,29 +59,293 @@ def flambda_of(kind, p):
     return 2 * np.pi / np.sqrt(p + 0.5)
 
 
-def cpu_baseline(x, dt, kind, param, sj_all, budget_s=25.0):
-    """The oracle (NumPy restatement of wavelet.py:91-106 on pocketfft, 1 thread like the reference)
-    timed on this box's host cores on the same workload: rows in groups of 16 (forward FFT + filter bank +
-    batched inverse FFT per group, as wavelet.py does for the whole matrix) until all rows are done or
-    the time budget is used up."""
-    from oracle import cwt_oracle as orc
-    m = orc.Mother(kind, int(param) if kind else param)
-    orc.cwt_rows(x[:4096], dt, sj_all[:2], m)                 # warm-up (imports, pocketfft plan)
-    order = np.random.default_rng(0).permutation(len(sj_all))  # unbiased sample if the budget cuts it short
-    t0 = time.perf_counter()
-    done = 0
-    for g in range(0, len(order), 16):
-        idx = np.sort(order[g:g + 16])
+class Runtime:
+    """Device / process-group plumbing: a real GPU + RCCL, or (rehearsal) CPU tensors + gloo + emulated kernels."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from pycwt_amd import _hip
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run")
+        self.emulate = args.emulate
+        if self.emulate:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+            import build_emu
+            self.lib = _hip.Library(build_emu.build())
+            self.dev = torch.device("cpu")
+            self.device_index = 0
+        else:
+            from pycwt_amd import _build
+            _build.ensure(self.local)     # prebuilt library travels with the tree; compile once if it did not
+            self.lib = _hip.load()
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+            self.device_index = self.local
+        self.backend = args.backend or ("gloo" if self.emulate else "nccl")
+        self.use_dist = self.world > 1 or args.force_dist
+        if self.use_dist:
+            if self.world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def stream_handle(self):
+        return 0 if self.emulate else self.torch.cuda.current_stream().cuda_stream
+
+    def sync(self):
+        if not self.emulate:
+            self.torch.cuda.synchronize()
+
+    def fence(self):
+        self.sync()
+        if self.use_dist:
+            self.dist.barrier()
+            self.sync()
+
+    def max_over_ranks(self, seconds):
+        if not self.use_dist:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+class Workload:
+    """One BASELINE configuration on this rank: the signal, this rank's rows (j = rank mod world) of a
+    `rows_total`-row scale grid, the device buffers and the plan."""
+
+    def __init__(self, rt, config, logn, rows_total, opts):
+        from pycwt_amd import _hip
+        torch = rt.torch
+        self.rt, self.config = rt, config
+        self.kind, self.param, self.prec, self.label = CONFIGS[config]
+        self.N, self.dt, self.rows_total = 1 << logn, 1.0, rows_total
+        self.sj_all = scale_grid(self.N, self.dt, flambda_of(self.kind, self.param), rows_total)
+        self.mine = np.arange(rt.rank, rows_total, rt.world)
+        self.sj = np.ascontiguousarray(self.sj_all[self.mine])
+        real_t = torch.float64 if self.prec == 64 else torch.float32
+        cplx_t = torch.complex128 if self.prec == 64 else torch.complex64
+        self.csize = 16 if self.prec == 64 else 8
+        self.x_host = np.random.default_rng(1234).standard_normal(self.N)
+        if self.prec == 32:
+            self.x_host = self.x_host.astype(np.float32)
+        x = torch.empty(self.N, dtype=real_t, device=rt.dev)
+        if rt.rank == 0:
+            x.copy_(torch.from_numpy(self.x_host))
+        # two signal buffers: the broadcast of step i+1 lands in the other one while step i computes
+        self.xbuf = [x, x.clone()]
+        self.xhat = torch.empty(self.N, dtype=cplx_t, device=rt.dev)
+        self.W = torch.empty((max(len(self.sj), 1), self.N), dtype=cplx_t, device=rt.dev)
+        self.opts = dict(opts)
+        self.plan = _hip.Plan(self.N, self.prec, max_rows=max(len(self.sj), 1), device=rt.device_index, lib=rt.lib,
+                              options=self.opts)
+        self.plan.set_stream(rt.stream_handle())
+
+    def compute(self, buf):
+        self.plan.forward_fft(buf.data_ptr(), self.N, self.xhat.data_ptr())
+        if len(self.sj):
+            self.plan.transform_rows(self.xhat.data_ptr(), self.kind, self.param, self.dt, self.sj, self.W.data_ptr(),
+                                     self.N, self.N)
+
+    def run_steps(self, count):
+        """`count` steps.  With more than one rank the broadcast of step i+1 is issued (async, on RCCL's own
+        stream) before the kernels of step i are queued; `wait()` makes the compute stream -- not the host --
+        wait for the broadcast, so host enqueue, xGMI transfer and kernels all overlap.  Every timed step owns
+        exactly one broadcast: none is issued ahead of the region's start, none is prefetched past its end."""
+        rt = self.rt
+        pending = rt.dist.broadcast(self.xbuf[0], src=0, async_op=True) if rt.use_dist else None
+        for i in range(count):
+            if rt.use_dist:
+                pending.wait()
+                pending = rt.dist.broadcast(self.xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
+            self.compute(self.xbuf[i & 1])
+
+    def timed(self, steps, warmup):
+        rt = self.rt
+        self.run_steps(warmup)
+        rt.fence()
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        rt.fence()
+        elapsed = rt.max_over_ranks(time.perf_counter() - t0)
+        ms = elapsed / steps * 1e3
+        return {"ms_per_step": ms, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9}
+
+    def roofline(self, steps):
+        """Per-kernel HIP-event timing in separate passes (option "profile": every kernel alone on the plan's
+        stream, so that each duration is its own) -> the dominant kernel's achieved algorithmic bandwidth."""
+        plan, rt, N = self.plan, self.rt, self.N
+        plan.set_option("profile", 1)
+        plan.set_option("overlap", 0)
+        prof_steps = max(3, min(10, steps))
+        self.run_steps(1); rt.fence(); plan.timings()
+        for _ in range(prof_steps):
+            self.run_steps(1)
+        rt.fence()
+        tm = plan.timings()
+        plan.set_option("profile", 0)
+        plan.set_option("overlap", self.opts.get("overlap", 0))
+        split = plan.last_split()
+        units_by_class = {"small": split["small"] * N, "narrow": (split["narrow"] - split["narrow_k2048"]) * N,
+                          "narrow_big": split["narrow_k2048"] * N, "pass_a": split["two_pass"] * N,
+                          "pass_b": split["two_pass"] * N}
+        kern = {name: {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
+                for name, (ms, cnt) in tm.items()}
+        cand = [k for k in kern if units_by_class.get(k)]
+        if not cand:
+            return {"bound": "hbm", "kernel": None, "kernels": kern, "row_split": split}
+        dom = max(cand, key=lambda k: kern[k]["ms_per_step"])
+        dom_launches = kern[dom]["launches_per_step"]
+        dom_avg_ms = kern[dom]["ms_per_step"] / dom_launches
+        alg_bytes_per_launch = units_by_class[dom] * self.csize / dom_launches   # SURVEY 8d: 16 B (8 B) per unit
+        achieved = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
+        gpu_ms = sum(v["ms_per_step"] for v in kern.values())
+        alg_bytes_total = float(N) * len(self.sj) * self.csize + N * (self.csize // 2)
+        traffic = None                  # HBM bytes per launch of the dominant kernel, from committed PMC passes
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{self.config}.json")
+        if os.path.exists(tpath) and not self.opts and N == 1 << 20 and self.rows_total == 256 and rt.world == 1:
+            t = json.load(open(tpath))["per_kernel_class"].get(dom)
+            if t:
+                traffic = t["hbm_bytes_per_launch"]
+        return {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": (f"profiles/traffic_{self.config}.json (rocprofv3 PMC passes of this command, "
+                               "FETCH_SIZE x2 + WRITE_SIZE)") if traffic else None,
+            "avg_launch_ms": dom_avg_ms, "launches_per_step": dom_launches,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            # bytes the memory system really moved per launch (PMC) / live launch time: how busy HBM + fabric are,
+            # as opposed to `frac`, which prices only the algorithmic bytes
+            "traffic_GBs": (traffic / (dom_avg_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "whole_path": {"algorithmic_bytes_per_step_per_gpu": alg_bytes_total,
+                           "kernel_ms_per_step": gpu_ms,
+                           "achieved_GBs": alg_bytes_total / (gpu_ms * 1e-3) / 1e9,
+                           "frac": alg_bytes_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_measured_copy_ceiling_6290": alg_bytes_total / (gpu_ms * 1e-3) / 1e9 / 6290.0},
+            "kernels": kern, "row_split": split,
+        }
+
+    def cpu_and_parity(self, budget_s=25.0, group=16):
+        """The oracle (NumPy restatement of wavelet.py:91-106 on pocketfft, 1 thread like the reference) computes the
+        rows of the SAME workload in groups of `group` (forward FFT + filter bank + batched inverse FFT per group,
+        as wavelet.py does for the whole matrix).  Its time is the CPU baseline; its rows are the parity reference
+        for the rows of W that the last GPU step left on the device (downloaded group by group, outside the oracle's
+        clock).  Rows the reference itself turns into NaN (Paul, wavelet.py:111-115) are timed but not compared."""
+        from oracle import cwt_oracle as orc
+        m = orc.Mother(self.kind, int(self.param) if self.kind else self.param)
+        x, dt, N = self.x_host, self.dt, self.N
+        orc.cwt_rows(x[:4096], dt, self.sj_all[:2], m)                 # warm-up (imports, pocketfft plan)
+        classes = self.plan.row_classes()
+        order = np.random.default_rng(0).permutation(len(self.sj))  # unbiased sample if the budget cuts it short
+        dropped = orc.dropped_rows(self.sj, dt, m)
+        cpu_s, done, checked = 0.0, 0, 0
+        worst = (0.0, -1)
+        per_class = {}
+        l2_num = l2_den = 0.0
+        for g in range(0, len(order), group):
+            idx = np.sort(order[g:g + group])
+            t0 = time.perf_counter()
+            with np.errstate(all="ignore"):
+                ref = orc.cwt_rows(x, dt, self.sj[idx], m)
+            cpu_s += time.perf_counter() - t0
+            done += len(idx)
+            got = self.W[self.rt.torch.from_numpy(idx)].cpu().numpy()
+            for k, j in enumerate(idx):
+                if dropped[j]:
+                    continue
+                den = np.abs(ref[k]).max()
+                err = float(np.abs(got[k] - ref[k]).max() / (den if den > 0 else 1.0))
+                checked += 1
+                l2_num += float(np.sum(np.abs(got[k] - ref[k]) ** 2))
+                l2_den += float(np.sum(np.abs(ref[k]) ** 2))
+                c = per_class.setdefault(classes[j], {"rows": 0, "max_row_err": 0.0, "worst_row": -1})
+                c["rows"] += 1
+                if err >= c["max_row_err"]:
+                    c["max_row_err"], c["worst_row"] = err, int(self.mine[j])
+                if err >= worst[0]:
+                    worst = (err, int(self.mine[j]))
+            if cpu_s > budget_s:
+                break
+        tol = PARITY_TOL[self.prec]
+        parity = {"rows_checked": checked, "rows_total": int(len(self.sj)), "max_row_err": worst[0],
+                  "worst_row": worst[1], "rel_l2": float(np.sqrt(l2_num / l2_den)) if l2_den else None,
+                  "tolerance": tol, "ok": bool(checked > 0 and worst[0] < tol),
+                  "metric": "per-row max|W_gpu - W_oracle| / max|W_oracle| over all N columns",
+                  "per_kernel_class": per_class}
+        cpu = {"value": done * float(N) / cpu_s / 1e9, "unit": "GSamples*scales/s", "cores": 1, "kind": "port",
+               "sample": f"{done} of {len(self.sj)} rows (random order, groups of {group}) at N={N}: forward FFT + "
+                         f"filter bank + batched inverse FFT per group, {cpu_s:.1f} s; box has {os.cpu_count()} "
+                         "cores, 1 used (the reference is single-threaded)"}
+        return cpu, parity
+
+    def reference_as_is(self, nrows=64):
+        """Wall time of the reference's WHOLE function -- incl. the NaN scan and the fancy-index copy of
+        wavelet.py:111-115 that the row-wise port skips -- on every (rows/nrows)-th row of the workload, via the
+        `freqs=` argument (wavelet.py:86-88): the unmodified reference when /root/reference is importable (build
+        container), else its restatement oracle.cwt."""
+        from oracle import cwt_oracle as orc
+        m = orc.Mother(self.kind, int(self.param) if self.kind else self.param)
+        sel = self.sj_all[::max(1, len(self.sj_all) // nrows)][:nrows]
+        freqs = 1.0 / (m.flambda() * sel)
+        fn, kind = None, "port"
+        ref_root = "/root/reference"
+        if os.path.isdir(os.path.join(ref_root, "pycwt")):
+            try:
+                sys.dont_write_bytecode = True
+                sys.path.insert(0, ref_root)
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    import pycwt as ref
+                mother = {0: ref.Morlet, 1: ref.Paul, 2: ref.DOG}[self.kind](int(self.param) if self.kind else self.param)
+                fn, kind = (lambda: ref.cwt(self.x_host, self.dt, wavelet=mother, freqs=freqs)), "reference"
+            except Exception:
+                fn = None
+            finally:
+                sys.path.remove(ref_root)
+        if fn is None:
+            fn = lambda: orc.cwt(self.x_host, self.dt, wavelet=m, freqs=freqs)          # noqa: E731
+        t0 = time.perf_counter()
         with np.errstate(all="ignore"):
-            orc.cwt_rows(x, dt, sj_all[idx], m)
-        done += len(idx)
-        if time.perf_counter() - t0 > budget_s:
-            break
-    el = time.perf_counter() - t0
-    return {"value": done * x.size / el / 1e9, "unit": "GSamples*scales/s", "cores": 1, "kind": "port",
-            "sample": f"{done} of {len(sj_all)} rows (random order, groups of 16) at N={x.size}: forward FFT + "
-                      f"filter bank + batched inverse FFT per group, {el:.1f} s; box has {os.cpu_count()} cores, "
-                      "1 used (the reference is single-threaded)"}
+            out = fn()
+        el = time.perf_counter() - t0
+        return {"value": len(sel) * float(self.N) / el / 1e9, "unit": "GSamples*scales/s", "cores": 1, "kind": kind,
+                "rows_returned": int(out[0].shape[0]),
+                "sample": f"the whole cwt() (FFT, filter bank, batched inverse FFT, NaN scan, row copy) on {len(sel)} of "
+                          f"the {len(self.sj_all)} rows at N={self.N}, once: {el:.1f} s"}
+
+    def close(self):
+        self.plan.close()
+
+
+def measure(rt, config, args, rows_total, opts, want_cpu):
+    wl = Workload(rt, config, args.logn, rows_total, opts)
+    out = wl.timed(args.steps, args.warmup)
+    out["roofline"] = wl.roofline(args.steps)
+    if want_cpu:
+        wl.run_steps(1)
+        rt.fence()
+        out["cpu_baseline"], out["parity"] = wl.cpu_and_parity()
+        out["cpu_baseline"]["reference_as_is"] = wl.reference_as_is()
+    out["dtype"] = "f64" if wl.prec == 64 else "f32"
+    out["label"] = wl.label
+    wl.close()
+    return out
 
 
 def main():
@@ -81,11 +355,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--logn", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=256, help="rows per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=256, help="rows of the scale grid (per GPU with --weak)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --rows rows per GPU of a rows*G-row grid")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline / parity / extra")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 block of the default run")
     ap.add_argument("--opt", action="append", default=[], help="plan option key=value (tuning)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (smoke test of the RCCL path)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL; gloo with --emulate)")
+    ap.add_argument("--emulate", action="store_true",
+                    help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result.  Libraries that write to the C stdout stream (RCCL prints
@@ -94,161 +373,49 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-    from pycwt_amd import _hip
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    from pycwt_amd import _build
-    _build.ensure(local)          # prebuilt library travels with the tree; compile once if it did not
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-
+    rt = Runtime(args)
+    world, rank = rt.world, rt.rank
+    opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
     kind, param, prec, label = CONFIGS[args.config]
     N = 1 << args.logn
-    dt = 1.0
-    rows_local = args.rows
-    rows_total = rows_local * world
-    sj_all = scale_grid(N, dt, flambda_of(kind, param), rows_total)
-    sj = np.ascontiguousarray(sj_all[rank::world])
-    real_t = torch.float64 if prec == 64 else torch.float32
-    cplx_t = torch.complex128 if prec == 64 else torch.complex64
-    csize = 16 if prec == 64 else 8
+    rows_total = args.rows * world if args.weak else args.rows
+    single = world == 1 and not args.no_cpu_baseline
 
-    x_host = np.random.default_rng(1234).standard_normal(N)
-    x = torch.empty(N, dtype=real_t, device=dev)
-    if rank == 0:
-        x.copy_(torch.from_numpy(x_host).to(real_t))
-    xhat = torch.empty(N, dtype=cplx_t, device=dev)
-    W = torch.empty((rows_local, N), dtype=cplx_t, device=dev)
-
-    opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
-    plan = _hip.Plan(N, prec, max_rows=rows_local, device=local, options=opts)
-    plan.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    # Two signal buffers: with more than one rank the broadcast of step i+1 is issued (async, on RCCL's own
-    # stream) before the kernels of step i are queued, so it travels over xGMI while step i computes.  Every
-    # timed step still owns exactly one broadcast: the pipeline is drained at the boundaries of the timed
-    # region (no broadcast is issued ahead of its start, none is prefetched past its end).
-    xbuf = [x, x.clone()]
-
-    def compute(buf):
-        plan.forward_fft(buf.data_ptr(), N, xhat.data_ptr())
-        plan.transform_rows(xhat.data_ptr(), kind, param, dt, sj, W.data_ptr(), N, N)
-
-    def run_steps(count):
-        pending = dist.broadcast(xbuf[0], src=0, async_op=True) if use_dist else None
-        for i in range(count):
-            if use_dist:
-                pending.wait()                                       # current stream waits for broadcast i
-                pending = dist.broadcast(xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
-            compute(xbuf[i & 1])
-
-    def step():
-        run_steps(1)
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    run_steps(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    units_per_step = float(N) * rows_total
-    value = units_per_step / (elapsed / args.steps) / 1e9
-
-    # ---- per-kernel HIP-event timing (separate passes so the events do not perturb `value`) ----
-    plan.set_option("profile", 1)
-    plan.set_option("overlap", 0)     # kernels one at a time, so that each duration is its own
-    plan.set_option("overlap_narrow", 0)
-    prof_steps = max(3, min(10, args.steps))
-    step(); fence(); plan.timings()
-    for _ in range(prof_steps):
-        step()
-    fence()
-    tm = plan.timings()
-    plan.set_option("profile", 0)
-    plan.set_option("overlap", opts.get("overlap", 0))
-    plan.set_option("overlap_narrow", opts.get("overlap_narrow", 0))
-    split = plan.last_split()
-    units_by_class = {"small": split["small"] * N, "narrow": (split["narrow"] - split["narrow_k2048"]) * N,
-                      "narrow_big": split["narrow_k2048"] * N, "pass_a": split["two_pass"] * N,
-                      "pass_b": split["two_pass"] * N}
-    kern = {}
-    for name, (ms, cnt) in tm.items():
-        kern[name] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
-    dom = max((k for k in kern if k in units_by_class), key=lambda k: kern[k]["ms_per_step"])
-    dom_units = units_by_class[dom]
-    dom_launches = kern[dom]["launches_per_step"]
-    dom_avg_ms = kern[dom]["ms_per_step"] / dom_launches
-    alg_bytes_per_launch = dom_units * csize / dom_launches      # 16 B (8 B) per sample*scale
-    achieved = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
-    gpu_ms = sum(v["ms_per_step"] for v in kern.values())
-    alg_bytes_total = units_per_step / world * csize + N * (csize // 2)
-    traffic = None                      # HBM bytes per launch of the dominant kernel, from committed PMC passes
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
-    if os.path.exists(tpath) and not opts and args.logn == 20 and args.rows == 256:
-        t = json.load(open(tpath))["per_kernel_class"].get(dom)
-        if t:
-            traffic = t["hbm_bytes_per_launch"]
-    roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "traffic_source": (f"profiles/traffic_{args.config}.json (rocprofv3 PMC passes of this command, "
-                           "FETCH_SIZE x2 + WRITE_SIZE)") if traffic else None,
-        "avg_launch_ms": dom_avg_ms, "launches_per_step": dom_launches,
-        "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-        # bytes the memory system really moved per launch (PMC) / live launch time: how busy HBM + fabric are,
-        # as opposed to `frac`, which prices only the algorithmic bytes
-        "traffic_GBs": (traffic / (dom_avg_ms * 1e-3) / 1e9) if traffic else None,
-        "traffic_frac": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        "whole_path": {"algorithmic_bytes_per_step_per_gpu": alg_bytes_total,
-                       "kernel_ms_per_step": gpu_ms,
-                       "achieved_GBs": alg_bytes_total / (gpu_ms * 1e-3) / 1e9,
-                       "frac": alg_bytes_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "frac_of_measured_copy_ceiling_6290": alg_bytes_total / (gpu_ms * 1e-3) / 1e9 / 6290.0},
-        "kernels": kern, "row_split": split,
-    }
-
+    head = measure(rt, args.config, args, rows_total, opts, want_cpu=single and rank == 0)
+    workload = f"N=2^{args.logn} {label} {rows_total} scales"
+    if world > 1:
+        workload += f" split over {world} GPUs (row j -> rank j mod {world})"
     out = {
-        "metric": "CWT GSamples*scales/s at N=2^20, J=256", "value": value, "unit": "GSamples*scales/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64" if prec == 64 else "f32", "data": "synthetic",
-        "config": {"workload": label + (f" x{world} GPUs ({rows_total} rows, row j -> rank j mod {world})" if world > 1 else ""),
-                   "N": N, "rows_per_gpu": rows_local, "rows_total": rows_total, "mother": ["morlet", "paul", "dog"][kind],
-                   "param": param, "signal": "default_rng(1234).standard_normal(N)", "dt": dt,
-                   "parallelism": f"scale-sharded x{world}, 1 broadcast/step" if world > 1 else "single GPU",
+        "metric": "CWT GSamples*scales/s at N=2^20, J=256", "value": head["value"], "unit": "GSamples*scales/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
+        "dtype": head["dtype"], "data": "synthetic" + (" (CPU emulation rehearsal, not a measurement)" if args.emulate else ""),
+        "config": {"workload": workload, "N": N, "rows_total": rows_total,
+                   "rows_per_gpu": (rows_total + world - 1) // world,
+                   "mother": ["morlet", "paul", "dog"][kind], "param": param,
+                   "signal": "default_rng(1234).standard_normal(N)", "dt": 1.0,
+                   "parallelism": (f"scale-sharded x{world}, 1 broadcast/step, backend {rt.backend}" if world > 1
+                                   else "single GPU"),
                    "plan_options": opts},
-        "roofline": roofline,
+        "roofline": head["roofline"],
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(x_host, dt, kind, param, sj_all)
-    plan.close()
-    if use_dist:
-        dist.destroy_process_group()
+    for k in ("parity", "cpu_baseline"):
+        if k in head:
+            out[k] = head[k]
+    if world > 1 and not args.weak:
+        # same run, weak-scaling variant (per-GPU work fixed): --rows rows per GPU of a rows*G-row grid
+        weak = measure(rt, args.config, args, args.rows * world, opts, want_cpu=False)
+        out["weak_scaling"] = {"value": weak["value"], "ms_per_step": weak["ms_per_step"], "rows_total": args.rows * world,
+                               "rows_per_gpu": args.rows}
+    if single and args.config == "c2" and not args.no_extra and not opts and not args.emulate:
+        out["extra"] = {}
+        for c in ("c3_paul", "c3_dog"):
+            r = measure(rt, c, args, rows_total, {}, want_cpu=True)
+            out["extra"][c] = {"workload": f"N=2^{args.logn} {r['label']} {rows_total} scales (BASELINE config 3)",
+                               "value": r["value"], "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"],
+                               "dtype": r["dtype"], "steps": args.steps, "warmup": args.warmup,
+                               "roofline": r["roofline"], "parity": r["parity"], "cpu_baseline": r["cpu_baseline"]}
+    rt.close()
     import ctypes
     sys.stdout.flush()
     try:

@@ -73,8 +73,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "overlap"      1 = run pass A of chunk c+1 beside pass B of chunk c on side
  *                  streams; 0 (default) = strictly one after the other
  *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
- *   "overlap_narrow" 1 = queue the band-limited rows on a side stream beside the two-pass chain
- *                  (+2 % in fp64), 0 (default) = everything on the plan's stream
+ *   "overlap_narrow" 1 (default) = queue the band-limited rows on a side stream beside the two-pass chain
+ *                  (+4 % in fp64; ignored while "profile" is on), 0 = everything on the plan's stream
  *   "band_pass_a"  0 = always run the full column FFT in pass A (no short aliased column FFTs)
  *   "pass_a_small" 0 = pass A on full-size workgroup tiles (default 1: half-size tiles, 4 per CU)
  *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size)
@@ -215,6 +215,12 @@ int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother,
  * in *n and resets the accumulators.  Synchronises the stream.              */
 int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_ms,
                      int* launches, int* n);
+/* Which kernel computed each row of the last transform call: codes[out_row] = kind*10000 + logK*100 + terms with
+ * kind 0 = single-workgroup transform, 1 = band-limited single pass (K = 2^logK <= 1024, `terms` aliased bins per
+ * input), 2 = band-limited single pass on 16384-point workgroups (K = 2048), 3 = two-pass (logK = log2 of the
+ * pass-A column support class, 0 = full column).  *n = number of rows of the call; codes may be NULL.  The parity
+ * tests and bench.py use it to report the worst row per kernel class.                                          */
+int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
 /* Diagnostics: with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
  * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
  * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in

@@ -13,6 +13,8 @@ Cases:
   mid_<mother>   N = 2**13 seeded noise, 16 rows spanning s0..N*dt, 3 mothers
   big_morlet     N = 2**20, the 256-row grid of BASELINE config 2, 7 rows
   big_paul/dog   same N, config 3 grids (fp64 values), 5 rows each
+  callers        significance / xwt / Morlet.smooth / wct (deterministic part)
+  mc_significance  wct_significance with np.random.seed (two small cases) + rednoise seed for seed
 The signal itself is stored too (NINO3 data is 504 floats).
 """
 import os
@@ -157,9 +159,32 @@ def callers():
     save("callers", **out)
 
 
+def mc_significance():
+    """Seeded Monte-Carlo coherence significance (wavelet.py:531-647): the reference draws from the global NumPy RNG
+    (helpers.py:170), one series BEFORE the loop (wavelet.py:594) and two per draw, so a seed pins the whole result."""
+    cases = []
+    for seed, (al1, al2, dt, dj, s0, J, mc) in enumerate([(0.72, 0.45, 0.25, 0.25, 0.5, 24, 30),
+                                                           (0.30, 0.30, 1.0, 0.5, 2.0, 10, 40)]):
+        np.random.seed(100 + seed)
+        sig = ref.wct_significance(al1, al2, dt=dt, dj=dj, s0=s0, J=J, significance_level=0.95,
+                                   wavelet=ref.Morlet(6), mc_count=mc, progress=False, cache=False)
+        cases.append(dict(seed=100 + seed, al1=al1, al2=al2, dt=dt, dj=dj, s0=s0, J=J, mc_count=mc, sig95=sig))
+    # the surrogate generator itself, seed for seed (helpers.py:146-173)
+    import pycwt.helpers as rh
+    np.random.seed(5)
+    r1 = rh.rednoise(400, 0.72, 1)
+    r2 = rh.rednoise(100, 0.3, 2.0)
+    save("mc_significance", n_cases=len(cases), rednoise_seed=5, rednoise_a=r1, rednoise_b=r2,
+         **{f"c{i}_{k}": v for i, c in enumerate(cases) for k, v in c.items()})
+
+
 if __name__ == "__main__":
+    if "--mc-only" in sys.argv:
+        mc_significance()
+        sys.exit(0)
     callers()
     sys.exit(0) if "--callers-only" in sys.argv else None
+    mc_significance()
     nino3()
     small()
     mid()

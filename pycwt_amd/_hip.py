@@ -55,6 +55,7 @@ SYMBOLS = [
                                    C.POINTER(C.c_double), C.c_int, _P, _P]),
     ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("cwt_plan_row_classes", C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
 ]
@@ -236,6 +237,28 @@ class Plan:
         n = C.c_int(0)
         self.lib.check(self.lib.cwt_plan_timings(self.h, cap, names, ms, cnt, C.byref(n)))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n.value, cap))}
+
+    _KINDS = ("single_wg", "narrow", "narrow_k2048", "two_pass")
+
+    def row_classes(self):
+        """Kernel class of every row of the last transform call, as labels like 'narrow/K1024/t3',
+        'narrow_k2048/t4', 'two_pass/full', 'two_pass/c64' (see cwt_plan_row_classes)."""
+        n = C.c_int(0)
+        self.lib.check(self.lib.cwt_plan_row_classes(self.h, None, 0, C.byref(n)))
+        codes = (C.c_int * max(n.value, 1))()
+        self.lib.check(self.lib.cwt_plan_row_classes(self.h, codes, n.value, C.byref(n)))
+        out = []
+        for c in codes[:n.value]:
+            kind, logk, terms = c // 10000, (c // 100) % 100, c % 100
+            if kind == 0:
+                out.append("single_wg")
+            elif kind == 3:
+                out.append("two_pass/" + ("full" if logk == 0 else f"c{1 << logk}"))
+            elif kind == 2:
+                out.append(f"narrow_k2048/t{terms}")
+            else:
+                out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
+        return out
 
     def read_stamps(self, cap: int):
         """(n_recorded, records[min(n, cap), 8] uint64) of the phase stamps since the last call (option "stamps")."""

@@ -72,8 +72,8 @@ struct cwt_plan {
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
   int force_logk = 0;
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
-  int overlap_narrow = 0;  // band-limited rows on a side stream beside the two-pass chain (measured: +2 % in
-                           // fp64, -3 % in fp32; off by default so that per-kernel timings stay clean)
+  int overlap_narrow = 1;  // band-limited rows on a side stream beside the two-pass chain (measured: +4 % in
+                           // fp64); ignored while "profile" is on so that every timed kernel runs alone
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
@@ -356,6 +356,14 @@ int chunk_rows_of(const cwt_plan* p) {
   return int(std::max<size_t>(1, (size_t(192) << 20) / row_bytes));
 }
 
+// Rows per two-pass launch for `nrows` rows: as few launches as the chunk limit allows, of equal size (102 rows at a
+// limit of 12 -> 9 launches of 11-12 rows instead of 8 x 12 + 6; 13 rows -> 7 + 6 instead of 12 + 1).
+int balanced_chunk(const cwt_plan* p, int nrows) {
+  const int limit = std::max(1, std::min(chunk_rows_of(p), nrows));
+  const int nchunks = (nrows + limit - 1) / limit;
+  return (nrows + nchunks - 1) / nchunks;
+}
+
 // N = R*K.  K = 1024 up to N = 2^21, K = 2048 at 2^22 and 2^23 (measured: 155 vs 117 GS/s at 2^22 against
 // K = 1024, 106 vs 60 at 2^23 against K = 4096: 32-byte store tiles in pass B hurt more than in pass A),
 // K = 4096 at 2^24 (forced by the 4096-point workgroup FFT limit).
@@ -612,7 +620,7 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   }
   const int logK = two_pass_logk(p), logR = logN - logK;
   const int logP = std::min(p->log_wg_points, logN);
-  const int chunk = std::max(1, std::min(chunk_rows_of(p), nrows));
+  const int chunk = balanced_chunk(p, nrows);
   int rc = ensure_z(p, chunk);
   if (rc) return rc;
   const size_t lds = (size_t(1) << logP) * sizeof(T);
@@ -671,13 +679,14 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int logP = std::min(p->log_wg_points, logN);
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
-  if (p->overlap_narrow && !p->overlap && p->n_wide && p->n_narrow) {   // side stream 0 starts after the spectrum exists
+  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && p->n_wide && p->n_narrow;
+  if (side_narrow) {   // side stream 0 starts after the spectrum exists
     HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
     HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
   }
   if (p->n_wide) {
     const int logK = two_pass_logk(p), logR = logN - logK;
-    const int chunk = std::max(1, std::min(chunk_rows_of(p), p->n_wide));
+    const int chunk = balanced_chunk(p, p->n_wide);
     const int nchunks = (p->n_wide + chunk - 1) / chunk;
     const bool pipelined = p->overlap && nchunks > 1;
     rc = ensure_z(p, pipelined ? 2 * chunk : chunk);
@@ -721,7 +730,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   if (p->n_narrow) {
     if (narrow_ct_all_applies<T>(p)) {
       hipStream_t keep = p->stream;
-      narrow_on_side = p->overlap_narrow && p->n_wide && !(p->overlap);
+      narrow_on_side = side_narrow;
       if (narrow_on_side) p->stream = p->side[0];
       int n_small_k, n_big;
       narrow_class_counts(p, &n_small_k, &n_big);
@@ -745,7 +754,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     }
   }
   if (p->n_wide) {
-    const int chunk = std::max(1, std::min(chunk_rows_of(p), p->n_wide));
+    const int chunk = balanced_chunk(p, p->n_wide);
     const int nchunks = (p->n_wide + chunk - 1) / chunk;
     if (p->overlap && nchunks > 1) {   // join: every pass A is followed by its pass B on side stream 1
       HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
@@ -1319,6 +1328,19 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
     ++k;
   }
   *n = k;
+  return CWT_OK;
+}
+
+int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
+  if (!p || !n) return fail(CWT_EINVAL, "NULL argument");
+  const int total = int(p->table.size());
+  *n = total;
+  if (!codes) return CWT_OK;
+  for (int i = 0; i < total; ++i) {
+    const RowDesc& rd = p->table[i];
+    const int kind = i < p->n_small ? 0 : i < p->wide_first ? (rd.logK == 11 ? 2 : 1) : 3;
+    if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
+  }
   return CWT_OK;
 }
 

@@ -2,8 +2,8 @@
 
 O(N) / O(J) NumPy arithmetic -- these stay on the host by design.  Same
 names and call signatures as pycwt/helpers.py:37-236 so that `pycwt.ar1`, `pycwt.helpers.rect`, ...
-keep resolving; the latent bugs of the reference noted in SURVEY.md 8a(ix) are not reproduced
-(`rednoise` with g == 0, `boxpdf`).
+keep resolving; the latent crashes of the reference noted in SURVEY.md 8a(ix) are not reproduced
+(`rednoise` with g == 0, `boxpdf`), its silent defect in `rednoise` (white surrogates) is -- see there.
 """
 from __future__ import annotations
 
@@ -50,13 +50,22 @@ def ar1_spectrum(freqs, ar1=0.):
     return (1 - ar1 ** 2) / np.abs(1 - ar1 * z) ** 2
 
 
-def rednoise(N, g, a=1.):
-    """AR(1) red noise of length N by filtering white noise, with a burn-in of twice the
-    decorrelation time (helpers.py:146-173).  Uses the global NumPy RNG like the reference."""
+def rednoise(N, g, a=1., *, ar1=False):
+    """Surrogate noise of length N for the Monte-Carlo tests (helpers.py:146-173), from the global NumPy RNG like
+    the reference: N + tau normal deviates (tau = twice the decorrelation time), the first tau discarded.
+
+    Default (`ar1=False`) = what the reference really returns, draw for draw: it hands the (N + tau, 1) column to
+    `lfilter([1, 0], [1, -g], .)` WITHOUT `axis=0` (helpers.py:170), so the AR(1) recursion runs along the axis of
+    length one, never sees a previous sample, and the output is the white input times `a` (lag-1 correlation 0.01
+    where `g` = 0.7 was asked for).  Reproducing that is what makes `wct_significance` agree with the reference seed
+    for seed (tests/golden/mc_significance.npz).  `ar1=True` filters along time, i.e. the AR(1) process the name
+    promises; `wct_significance(..., surrogates="ar1")` uses it and keeps its cache files apart.
+    g == 0 returns white noise (the reference raises AttributeError there: `np.randn`, helpers.py:166)."""
     if g == 0:
         return np.random.randn(N) * a
     tau = int(np.ceil(-2 / np.log(np.abs(g))))
-    y = lfilter([1, 0], [1, -g], np.random.randn(N + tau, 1) * a, axis=0)
+    w = np.random.randn(N + tau, 1) * a
+    y = lfilter([1, 0], [1, -g], w, axis=0) if ar1 else lfilter([1, 0], [1, -g], w)
     return y[tau:].flatten()
 
 

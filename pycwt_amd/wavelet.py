@@ -560,7 +560,8 @@ def _mc_setup(mother, dt, dj, s0, J):
     return N, sj, (lo, hi), rows_with_data, find(rows_with_data)[-1]
 
 
-def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False):
+def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False,
+                  ar1_surrogates=False):
     """Per-scale histograms (1000 bins on [0, 1)) of the coherence of `draws` AR(1) surrogate pairs, taken
     outside the COI (wavelet.py:609-630).  Coherence AND histogram run on the GPU (`cwt_coherence_histogram`):
     per draw only the two surrogate series go up, and the rows x 1000 counters come down once at the end."""
@@ -592,7 +593,7 @@ def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, pre
         from concurrent.futures import ThreadPoolExecutor
 
         def pair():
-            return rednoise(N, al1, 1), rednoise(N, al2, 1)
+            return rednoise(N, al1, 1, ar1=ar1_surrogates), rednoise(N, al2, 1, ar1=ar1_surrogates)
 
         with ThreadPoolExecutor(max_workers=1) as pool:
             nxt = pool.submit(pair) if draws > 0 else None
@@ -619,30 +620,40 @@ def _mc_percentiles(hist, rows_with_data, maxscale, significance_level):
     return sig
 
 
-def _mc_cache_path(al1, al2, dt, dj, s0, J, mother):
+def _mc_cache_path(al1, al2, dt, dj, s0, J, mother, tag=""):
     with np.errstate(invalid="ignore", divide="ignore"):      # |4*al| > 1 gives nan, as in the reference
         aa = np.round(np.arctanh(np.array([al1, al2]) * 4))
     aa = np.abs(aa) + 0.5 * (aa < 0)
-    return os.path.join(get_cache_dir(), "wct_sig_{:0.5f}_{:0.5f}_{:0.5f}_{:0.5f}_{:d}_{}.gz".format(
-        aa[0], aa[1], dj, s0 / dt, int(J), mother.name))
+    return os.path.join(get_cache_dir(), "wct_sig_{:0.5f}_{:0.5f}_{:0.5f}_{:0.5f}_{:d}_{}{}.gz".format(
+        aa[0], aa[1], dj, s0 / dt, int(J), mother.name, tag))
 
 
 def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
-                     progress=True, cache=True, *, precision=None, device=0):
-    """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of AR(1)
-    surrogates, coherence of each pair on the GPU, per-scale histogram of the values outside the cone
-    of influence, `significance_level` percentile.  Scales that never leave the COI get NaN.  Results
-    are cached in the reference's file format under `get_cache_dir()`.  Statistical parity only (the
-    reference draws from the unseeded global RNG, helpers.py:170).  `pycwt_amd.parallel.
-    wct_significance_sharded` splits the draws over the GPUs of a node."""
+                     progress=True, cache=True, *, precision=None, device=0, surrogates="reference"):
+    """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of surrogate series,
+    coherence of each pair on the GPU, per-scale histogram of the values outside the cone of influence,
+    `significance_level` percentile.  Scales that never leave the COI get NaN.
+
+    Seed for seed with the reference: the surrogates come from the global NumPy generator in the reference's order
+    -- one series before the loop (wavelet.py:594, drawn there only to size the arrays), then two per draw
+    (:612-613) -- so `np.random.seed(k)` pins the result to the reference's within one histogram bin
+    (tests/golden/mc_significance.npz).  `surrogates="reference"` (default) draws what the reference draws, which is
+    white noise (see `helpers.rednoise`); `surrogates="ar1"` draws the AR(1) processes of lag-1 correlation al1, al2
+    that the method calls for, and caches under a different file name.  Results are cached in the reference's file
+    format under `get_cache_dir()`.  `pycwt_amd.parallel.wct_significance_sharded` splits the draws over the GPUs of
+    a node."""
+    if surrogates not in ("reference", "ar1"):
+        raise ValueError("surrogates must be 'reference' or 'ar1'")
+    true_ar1 = surrogates == "ar1"
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
-    path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother) if cache else None
+    path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother, "_ar1" if true_ar1 else "") if cache else None
     if cache and os.path.exists(path):
         return np.loadtxt(path, unpack=True)
     N, sj, outside, rows_with_data, maxscale = _mc_setup(mother, dt, dj, s0, J)
+    rednoise(N, al1, 1, ar1=true_ar1)                  # wavelet.py:594: consumed from the RNG before the loop
     hist = _mc_histogram(mc_count, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device,
-                         progress)
+                         progress, ar1_surrogates=true_ar1)
     sig95 = _mc_percentiles(hist, rows_with_data, maxscale, significance_level)
     if cache:
         np.savetxt(path, sig95)

@@ -1,0 +1,61 @@
+"""The driver's bench contract, rehearsed on CPU: bench.py is launched exactly as the driver launches it (plain for
+N = 1, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` for N > 1) with
+`--emulate --backend gloo`, i.e. the real kernels on the CPU emulation of the HIP runtime and gloo instead of RCCL.
+Checks arguments, environment handling, the one-JSON-line stdout contract and the fields the judge reads; the
+numbers themselves mean nothing here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run(cmd):
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout            # stdout carries the JSON line and nothing else
+    return json.loads(lines[0])
+
+
+def test_single_rank_line_has_parity_and_cpu_baseline(emu_library):
+    d = run([sys.executable, "bench.py", "--emulate", "--logn", "13", "--rows", "12", "--steps", "2", "--warmup", "1"])
+    for k in CONTRACT + ["parity", "cpu_baseline"]:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64"
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    par = d["parity"]
+    assert par["rows_checked"] == 12 and par["ok"] and par["max_row_err"] < 1e-11
+    assert sum(c["rows"] for c in par["per_kernel_class"].values()) == 12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["cpu_baseline"]["reference_as_is"]["kind"] in ("reference", "port")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.parametrize("world", [2])
+def test_multi_rank_launch_as_the_driver_does(emu_library, world):
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+             "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", str(world),
+             "--steps", "2", "--warmup", "1", "--emulate", "--backend", "gloo", "--logn", "13", "--rows", "12"])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == world and d["scaling"] == "strong"
+    assert d["config"]["rows_total"] == 12 and d["config"]["rows_per_gpu"] == 6
+    assert d["weak_scaling"]["rows_total"] == 12 * world and d["weak_scaling"]["rows_per_gpu"] == 12
+    assert "parity" not in d and "cpu_baseline" not in d          # rank 0 at N = 1 only
+    assert d["value"] > 0 and d["weak_scaling"]["value"] > 0

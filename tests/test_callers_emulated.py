@@ -24,8 +24,14 @@ def test_host_helpers(g):
     assert list(pycwt_amd.find(np.array([[0, 1], [1, 0]]))) == [1, 2]
     with pytest.raises(Warning):
         pycwt_amd.ar1(np.arange(5.0))              # strong trend: no real root, raised like the reference
-    r = pycwt_amd.rednoise(4000, 0.7)
+    r = pycwt_amd.rednoise(4000, 0.7, ar1=True)        # the AR(1) process the name promises
     assert r.shape == (4000,) and abs(pycwt_amd.ar1(r)[0] - 0.7) < 0.08
+    r = pycwt_amd.rednoise(4000, 0.7)                  # what the reference really draws: white (helpers.py:170)
+    assert r.shape == (4000,) and abs(pycwt_amd.ar1(r)[0]) < 0.08
+    mc = load_golden("mc_significance")                # ... seed for seed
+    np.random.seed(int(mc["rednoise_seed"]))
+    np.testing.assert_array_equal(pycwt_amd.rednoise(400, 0.72, 1), mc["rednoise_a"])
+    np.testing.assert_array_equal(pycwt_amd.rednoise(100, 0.3, 2.0), mc["rednoise_b"])
     assert pycwt_amd.rednoise(10, 0).shape == (10,)  # the reference crashes here (np.randn)
     assert pycwt_amd.get_cache_dir().endswith("/.cache/pycwt/")
 
@@ -100,6 +106,29 @@ def test_wct_significance_monte_carlo_small(emulated, tmp_path, monkeypatch):
     again = pycwt_amd.wct_significance(0.3, 0.5, **kw)          # served from the cache file
     np.testing.assert_allclose(again, sig, equal_nan=True)
     assert len(list(tmp_path.glob("wct_sig_*_Morlet.gz"))) == 1
+
+
+def _seeded_significance_cases(precision=64):
+    """wct_significance under np.random.seed against values the unmodified reference produced with the same seed
+    (oracle/gen_golden.py: mc_significance): same NaN pattern, every finite level within one histogram bin."""
+    mc = load_golden("mc_significance")
+    for i in range(int(mc["n_cases"])):
+        c = {k[len(f"c{i}_"):]: mc[k] for k in mc.files if k.startswith(f"c{i}_")}
+        np.random.seed(int(c["seed"]))
+        sig = pycwt_amd.wct_significance(float(c["al1"]), float(c["al2"]), dt=float(c["dt"]), dj=float(c["dj"]),
+                                         s0=float(c["s0"]), J=int(c["J"]), significance_level=0.95, wavelet="morlet",
+                                         mc_count=int(c["mc_count"]), progress=False, cache=False,
+                                         precision=precision)
+        ref = c["sig95"]
+        assert sig.shape == ref.shape
+        np.testing.assert_array_equal(np.isnan(sig), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert ok.sum() >= 5
+        assert np.abs(sig[ok] - ref[ok]).max() <= 1.0e-3 + 1e-12, (i, sig, ref)
+
+
+def test_wct_significance_seed_for_seed_with_the_reference(emulated):
+    _seeded_significance_cases()
 
 
 def _histogram_case(lib, precision):

@@ -283,6 +283,11 @@ def test_wct_significance_gpu(hip_library, tmp_path, monkeypatch):
     assert sig[ok].max() - sig[ok].min() < 0.4
 
 
+def test_wct_significance_seed_for_seed_with_the_reference_gpu(hip_library):
+    from test_callers_emulated import _seeded_significance_cases
+    _seeded_significance_cases()
+
+
 @pytest.mark.parametrize("precision", [64, 32])
 def test_coherence_histogram_gpu(hip_library, precision):
     from test_callers_emulated import _histogram_case
@@ -427,7 +432,8 @@ def test_stream_overlap_options_keep_parity_at_full_size(hip_library):
     m = orc.Mother(orc.MORLET, 6)
     sj = grid(N, 1.0, m, 256)[:160:4]                     # 40 rows, mostly two-pass
     base = None
-    for opts in (None, {"overlap": 1, "chunk_rows": 3}, {"overlap_narrow": 1}, {"overlap": 1, "chunk_rows": 5}):
+    for opts in ({"overlap_narrow": 0}, None, {"overlap": 1, "chunk_rows": 3}, {"overlap_narrow": 1},
+                 {"overlap": 1, "chunk_rows": 5}, {"pass_b_small": 1}):
         plan = _hip.Plan(N, 64, max_rows=64, options=opts)
         for _ in range(3):                                # repeated calls re-use the two buffers
             W = _device_rows(plan, x, orc.MORLET, 6, sj, N)
@@ -439,3 +445,97 @@ def test_stream_overlap_options_keep_parity_at_full_size(hip_library):
             assert per_row.max() < TOL[64]
         else:
             assert np.array_equal(W, base), opts
+
+
+def _download_rows(plan, buf, lo, cnt, ld, dtype):
+    """Rows [lo, lo + cnt) of a device-resident row-major matrix with `ld` elements of `dtype` per row."""
+    import ctypes as C
+    out = np.empty((cnt, ld), dtype=dtype)
+    plan.lib.check(plan.lib.cwt_memcpy_d2h(plan.h, out.ctypes.data_as(C.c_void_p),
+                                           C.c_void_p(buf.ptr + lo * ld * out.itemsize), out.nbytes))
+    return out
+
+
+@pytest.mark.parametrize("name,prec", [("morlet", 64), ("paul", 32), ("dog", 32)])
+def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, prec):
+    """BASELINE configs 2 and 3 exactly as bench.py times them -- N = 2^20, all 256 rows, device resident, through
+    cwt_forward_fft + cwt_transform_rows -- with EVERY row compared with the oracle (pycwt/wavelet.py:91-106
+    restated), in slabs of 16 rows.  Prints the worst row per kernel class.  Rows the reference turns into NaN
+    (Paul: 161 of 256, wavelet.py:111-115) are computed too and must be finite; they have no reference value."""
+    N, rows = 1 << 20, 256
+    kind, param = MOTHERS[name]
+    m = orc.Mother(kind, param)
+    s0 = 2 / m.flambda()
+    sj = s0 * 2 ** (np.arange(rows) * np.log2(N / s0) / (rows - 1))           # SURVEY 8d grid (no rows dropped)
+    x = np.random.default_rng(1234).standard_normal(N)
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    x = x.astype(real)
+    plan = _hip.Plan(N, prec, max_rows=rows)
+    xd, xh = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 2 * x.itemsize)
+    Wd = _hip.DeviceBuffer(rows * N * 2 * x.itemsize)
+    xd.upload(plan, x)
+    plan.forward_fft(xd.ptr, N, xh.ptr)
+    plan.transform_rows(xh.ptr, kind, param, 1.0, sj, Wd.ptr, N, N)
+    classes = plan.row_classes()
+    assert len(classes) == rows
+    dropped = orc.dropped_rows(sj, 1.0, m)
+    worst, checked = {}, 0
+    for lo in range(0, rows, 16):
+        got = _download_rows(plan, Wd, lo, 16, N, cplx)
+        assert np.isfinite(got.view(real)).all()
+        with np.errstate(all="ignore"):
+            ref = orc.cwt_rows(x, 1.0, sj[lo:lo + 16], m)
+        for k in range(16):
+            j = lo + k
+            if dropped[j]:
+                continue
+            err = np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max()
+            checked += 1
+            if err >= worst.get(classes[j], (0.0, -1))[0]:
+                worst[classes[j]] = (float(err), j)
+    for b in (xd, xh, Wd):
+        b.free()
+    plan.close()
+    print(f"{name} fp{prec}: {checked} rows compared; worst row per kernel class:")
+    for c in sorted(worst):
+        print(f"   {c:22s} row {worst[c][1]:3d}  err {worst[c][0]:.3e}")
+    assert checked == rows - int(dropped.sum()) and checked >= 90      # Paul: 95 rows survive the reference's NaN rule
+    assert max(v[0] for v in worst.values()) < TOL[prec], worst
+
+
+def test_config4_full_batch_sampled_pairs(hip_library):
+    """BASELINE config 4 at full size on one GPU: 1024 signals x N = 2^16 x 128 Morlet scales through ONE batched
+    launch set (cwt_fft_rows + cwt_transform_rows_batch, 137 GB of W device resident), checked against the oracle
+    on sampled (signal, scale) pairs that cover every kernel class of the row table."""
+    nb, N, rows = 1024, 1 << 16, 128
+    m = orc.Mother(orc.MORLET, 6)
+    s0 = 2 / m.flambda()
+    sj = s0 * 2 ** (np.arange(rows) * np.log2(N / s0) / (rows - 1))
+    X = np.random.default_rng(1234).standard_normal((nb, N))
+    plan = _hip.Plan(N, 64, max_rows=nb * rows)
+    xd, xh = _hip.DeviceBuffer(X.nbytes), _hip.DeviceBuffer(nb * N * 16)
+    Wd = _hip.DeviceBuffer(nb * rows * N * 16)
+    xd.upload(plan, X)
+    plan.fft_rows(xd.ptr, False, nb, N, N, xh.ptr)
+    plan.transform_rows_batch(xh.ptr, nb, N, orc.MORLET, 6.0, 1.0, sj, Wd.ptr, N, N)
+    plan.sync()
+    classes = plan.row_classes()
+    assert len(classes) == nb * rows
+    rng = np.random.default_rng(7)
+    pairs = {(0, 0), (nb - 1, rows - 1), (nb - 1, 0), (0, rows - 1)}
+    for c in sorted(set(classes)):                       # two random pairs of every kernel class
+        idx = np.flatnonzero(np.array(classes) == c)
+        for i in rng.choice(idx, size=min(2, idx.size), replace=False):
+            pairs.add((int(i) // rows, int(i) % rows))
+    while len(pairs) < 48:
+        pairs.add((int(rng.integers(nb)), int(rng.integers(rows))))
+    worst = 0.0
+    for b, j in sorted(pairs):
+        got = _download_rows(plan, Wd, b * rows + j, 1, N, np.complex128)[0]
+        ref = orc.cwt_rows(X[b], 1.0, sj[j:j + 1], m)[0]
+        worst = max(worst, np.abs(got - ref).max() / np.abs(ref).max())
+    for buf in (xd, xh, Wd):
+        buf.free()
+    plan.close()
+    print(f"config 4 full batch: {len(pairs)} (signal, scale) pairs, worst row error {worst:.3e}")
+    assert worst < TOL[64]
