@@ -7,7 +7,9 @@ or no GPU is visible, the import / call fails loudly.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -110,8 +112,21 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _locked(method):
+    """Serialise the calls of one plan: the C plan is not thread-safe (shared row table, workspaces, stream) and
+    ctypes drops the GIL during a call.  Re-entrant, so a caller may hold `plan.lock` across a whole
+    upload -> transform -> download sequence while the methods take it again."""
+    @functools.wraps(method)
+    def wrapper(self, *a, **kw):
+        with self.lock:
+            return method(self, *a, **kw)
+    return wrapper
+
+
 class Plan:
-    """One (device, nfft, precision) plan; thin RAII wrapper over the C ABI."""
+    """One (device, nfft, precision) plan; thin RAII wrapper over the C ABI.  Every method holds `self.lock`
+    (an RLock) for the duration of its C call; multi-call sequences that must not interleave with another
+    thread's (everything in pycwt_amd.wavelet) hold it around the sequence."""
 
     def __init__(self, nfft: int, precision: int = 64, max_rows: int = 1024, device: int = 0,
                  lib: Library | None = None, options: dict | None = None):
@@ -122,6 +137,7 @@ class Plan:
         self.max_rows = int(max_rows)
         self.real = np.float64 if precision == 64 else np.float32
         self.cplx = np.complex128 if precision == 64 else np.complex64
+        self.lock = threading.RLock()
         h = _P()
         self.lib.check(self.lib.cwt_plan_create(C.byref(h), device, self.nfft, self.precision, self.max_rows))
         self.h = h
@@ -129,7 +145,11 @@ class Plan:
             self.set_option(k, v)
 
     def close(self):
-        h, self.h = getattr(self, "h", None), None
+        lock = getattr(self, "lock", None)
+        if lock is None:                     # __init__ failed before the handle existed
+            return
+        with lock:
+            h, self.h = getattr(self, "h", None), None
         if h:
             try:
                 self.lib.cwt_plan_destroy(h)
@@ -138,25 +158,31 @@ class Plan:
 
     __del__ = close
 
+    @_locked
     def set_option(self, key: str, value: int):
         self.lib.check(self.lib.cwt_plan_set_option(self.h, key.encode(), int(value)))
 
+    @_locked
     def set_stream(self, stream_handle: int):
         self.lib.check(self.lib.cwt_plan_set_stream(self.h, _P(stream_handle)))
 
+    @_locked
     def sync(self):
         self.lib.check(self.lib.cwt_plan_sync(self.h))
 
     # -- device-resident entry points (raw device addresses as ints) --
+    @_locked
     def forward_fft(self, x_dev: int, n0: int, xhat_dev: int):
         self.lib.check(self.lib.cwt_forward_fft(self.h, _P(x_dev), n0, _P(xhat_dev)))
 
+    @_locked
     def transform_rows(self, xhat_dev: int, mother: int, param: float, dt: float, scales, W_dev: int,
                        ldw: int, ncols: int):
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
 
+    @_locked
     def transform_rows_batch(self, xhat_dev: int, nbatch: int, xhat_ld: int, mother: int, param: float,
                              dt: float, scales, W_dev: int, ldw: int, ncols: int):
         s = np.ascontiguousarray(scales, dtype=np.float64)
@@ -164,6 +190,7 @@ class Plan:
                                                          float(param), float(dt), _dptr(s), s.size, _P(W_dev),
                                                          ldw, ncols))
 
+    @_locked
     def transform_rows_table(self, xhat_dev: int, table_dev: int, k_lo, nband, W_dev: int, ldw: int, ncols: int):
         k = np.ascontiguousarray(k_lo, dtype=np.int32)
         b = np.ascontiguousarray(nband, dtype=np.int32)
@@ -171,10 +198,12 @@ class Plan:
             self.h, _P(xhat_dev), _P(table_dev), k.ctypes.data_as(C.POINTER(C.c_int)),
             b.ctypes.data_as(C.POINTER(C.c_int)), k.size, _P(W_dev), ldw, ncols))
 
+    @_locked
     def fft_rows(self, in_dev: int, in_complex: bool, nrows: int, in_ld: int, ncols_in: int, spec_dev: int):
         self.lib.check(self.lib.cwt_fft_rows(self.h, _P(in_dev), int(in_complex), nrows, in_ld, ncols_in,
                                              _P(spec_dev)))
 
+    @_locked
     def filter_rows(self, spec_dev: int, spec_ld: int, mother: int, param: float, a, amp, W_dev: int, ldw: int,
                     ncols: int):
         a = np.ascontiguousarray(a, dtype=np.float64)
@@ -183,41 +212,50 @@ class Plan:
         self.lib.check(self.lib.cwt_filter_rows(self.h, _P(spec_dev), spec_ld, mother, float(param), _dptr(a),
                                                 _dptr(ar), _dptr(ai), a.size, _P(W_dev), ldw, ncols))
 
+    @_locked
     def boxcar_scales(self, in_dev: int, nrows: int, ld: int, ncols: int, win, out_dev: int):
         w = np.ascontiguousarray(win, dtype=np.float64)
         self.lib.check(self.lib.cwt_boxcar_scales(self.h, _P(in_dev), nrows, ld, ncols, _dptr(w), w.size, _P(out_dev)))
 
+    @_locked
     def wct_products(self, W1_dev: int, W2_dev: int, scales, ld: int, ncols: int, P_dev: int, C_dev: int,
                      angle_dev: int):
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_wct_products(self.h, _P(W1_dev), _P(W2_dev), _dptr(s), s.size, ld, ncols,
                                                  _P(P_dev), _P(C_dev), _P(angle_dev)))
 
+    @_locked
     def wct_coherence(self, S_dev: int, S12_dev: int, nrows: int, ld: int, ncols: int, out_dev: int):
         self.lib.check(self.lib.cwt_wct_coherence(self.h, _P(S_dev), _P(S12_dev), nrows, ld, ncols, _P(out_dev)))
 
+    @_locked
     def icwt_reduce(self, W_dev: int, ldw: int, ncols: int, scales, coeff: float, out_dev: int):
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_icwt_reduce(self.h, _P(W_dev), ldw, ncols, s.size, _dptr(s),
                                                 float(coeff), _P(out_dev)))
 
+    @_locked
     def reduce_scales(self, W_dev: int, ldw: int, ncols: int, weights, power: bool, coeff: float, out_dev: int):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self.lib.check(self.lib.cwt_reduce_scales(self.h, _P(W_dev), ldw, ncols, w.size, _dptr(w), int(power),
                                                   float(coeff), _P(out_dev)))
 
+    @_locked
     def time_mean_power(self, W_dev: int, ldw: int, ncols: int, nrows: int, out_dev: int):
         self.lib.check(self.lib.cwt_time_mean_power(self.h, _P(W_dev), ldw, ncols, nrows, _P(out_dev)))
 
+    @_locked
     def cross_spectrum(self, W1_dev: int, W2_dev: int, nrows: int, ld: int, ncols: int, out_dev: int):
         self.lib.check(self.lib.cwt_cross_spectrum(self.h, _P(W1_dev), _P(W2_dev), nrows, ld, ncols, _P(out_dev)))
 
+    @_locked
     def coherence_histogram(self, r2_dev: int, ld: int, nrows: int, lo_dev: int, hi_dev: int, max_span: int,
                             nbins: int, hist_dev: int):
         self.lib.check(self.lib.cwt_coherence_histogram(self.h, _P(r2_dev), ld, nrows, _P(lo_dev), _P(hi_dev),
                                                         int(max_span), nbins, _P(hist_dev)))
 
     # -- host convenience --
+    @_locked
     def execute_host(self, x, mother: int, param: float, dt: float, scales, want_W=True, want_xhat=True):
         x = np.ascontiguousarray(x, dtype=self.real)
         s = np.ascontiguousarray(scales, dtype=np.float64)
@@ -229,6 +267,7 @@ class Plan:
             W.ctypes.data_as(_P) if want_W else None, xhat.ctypes.data_as(_P) if want_xhat else None))
         return W, xhat
 
+    @_locked
     def timings(self):
         cap = 16
         names = (C.c_char_p * cap)()
@@ -240,6 +279,7 @@ class Plan:
 
     _KINDS = ("single_wg", "narrow", "narrow_k2048", "two_pass")
 
+    @_locked
     def row_classes(self):
         """Kernel class of every row of the last transform call, as labels like 'narrow/K1024/t3',
         'narrow_k2048/t4', 'two_pass/full', 'two_pass/c64' (see cwt_plan_row_classes)."""
@@ -260,6 +300,7 @@ class Plan:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out
 
+    @_locked
     def read_stamps(self, cap: int):
         """(n_recorded, records[min(n, cap), 8] uint64) of the phase stamps since the last call (option "stamps")."""
         out = np.zeros((cap, 8), dtype=np.uint64)
@@ -267,6 +308,7 @@ class Plan:
         self.lib.check(self.lib.cwt_plan_read_stamps(self.h, out.ctypes.data_as(_P), cap, C.byref(n)))
         return n.value, out[:min(n.value, cap)]
 
+    @_locked
     def last_split(self):
         c = (C.c_int * 4)()
         self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
@@ -297,10 +339,12 @@ class DeviceBuffer:
     def upload(self, plan: Plan, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         assert arr.nbytes <= self.nbytes
-        self.lib.check(self.lib.cwt_memcpy_h2d(plan.h, _P(self.ptr), arr.ctypes.data_as(_P), arr.nbytes))
+        with plan.lock:
+            self.lib.check(self.lib.cwt_memcpy_h2d(plan.h, _P(self.ptr), arr.ctypes.data_as(_P), arr.nbytes))
 
     def download(self, plan: Plan, shape, dtype) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        self.lib.check(self.lib.cwt_memcpy_d2h(plan.h, out.ctypes.data_as(_P), _P(self.ptr), out.nbytes))
+        with plan.lock:
+            self.lib.check(self.lib.cwt_memcpy_d2h(plan.h, out.ctypes.data_as(_P), _P(self.ptr), out.nbytes))
         return out

@@ -84,24 +84,34 @@ struct cwt_plan {
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
   int twn_shift = 0;
-  RowDesc* rows_dev = nullptr;
-  RowDesc* rows_pinned = nullptr;
   void* weights_dev = nullptr;
-  void* weights_pinned = nullptr;
+  void* weights_pinned[2] = {nullptr, nullptr};   // staging of upload_reals, used in turn
+  hipEvent_t weights_ev[2] = {nullptr, nullptr};  // recorded after the copy out of weights_pinned[i]
+  int weights_turn = 0;
   void* Z = nullptr;
   size_t z_bytes = 0;
   // buffers of cwt_execute_host
   void* hx = nullptr; size_t hx_bytes = 0;
   void* hxhat = nullptr; size_t hxhat_bytes = 0;
   void* hW = nullptr; size_t hW_bytes = 0;
-  // cache of the last row table (skip re-upload when the call repeats)
-  std::vector<double> last_scales;
-  int last_mother = -1; double last_param = 0, last_dt = 0;
-  bool table_valid = false;
-  std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
+  // Classified row tables with their device copies.  Two slots, least recently used one rebuilt on a miss, so that
+  // callers that alternate between two kinds of calls with fixed arguments (the coherence pipeline: cwt rows, then
+  // the smoothing filter rows, draw after draw) build and upload each table once.  No host synchronisation on the
+  // way: every slot has its own pinned staging buffer and an event that marks its last copy as done.
   struct Group { int logK; int first; int count; int nterms; };
-  std::vector<Group> narrow_groups;
-  int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
+  struct RowTable {
+    std::vector<double> key;             // the call it was built from; empty = not valid
+    std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
+    std::vector<Group> narrow_groups;
+    int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
+    RowDesc* rows_dev = nullptr;
+    RowDesc* rows_pinned = nullptr;
+    hipEvent_t uploaded = nullptr;
+    uint64_t used = 0;
+  };
+  RowTable slots[2];
+  RowTable* rt = &slots[0];
+  uint64_t tick = 0;
   int split[4] = {0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024, two-pass, band-limited K = 2048
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
@@ -324,30 +334,30 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   auto group_key = [](const RowDesc& x) { return (x.logK == 11 ? 1000 : 0) + x.logK + 100 * x.nterms; };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
-  p->table.clear();
-  p->narrow_groups.clear();
-  p->table.insert(p->table.end(), small_rows.begin(), small_rows.end());
+  p->rt->table.clear();
+  p->rt->narrow_groups.clear();
+  p->rt->table.insert(p->rt->table.end(), small_rows.begin(), small_rows.end());
   for (size_t i = 0; i < narrow_rows.size(); ++i) {
     const int nt = narrow_rows[i].nterms;
-    if (p->narrow_groups.empty() || p->narrow_groups.back().logK != narrow_rows[i].logK ||
-        p->narrow_groups.back().nterms != nt)
-      p->narrow_groups.push_back({narrow_rows[i].logK, int(p->table.size()), 0, nt});
-    p->narrow_groups.back().count++;
-    p->table.push_back(narrow_rows[i]);
+    if (p->rt->narrow_groups.empty() || p->rt->narrow_groups.back().logK != narrow_rows[i].logK ||
+        p->rt->narrow_groups.back().nterms != nt)
+      p->rt->narrow_groups.push_back({narrow_rows[i].logK, int(p->rt->table.size()), 0, nt});
+    p->rt->narrow_groups.back().count++;
+    p->rt->table.push_back(narrow_rows[i]);
   }
-  p->wide_first = int(p->table.size());
-  p->table.insert(p->table.end(), wide_rows.begin(), wide_rows.end());
-  p->n_small = int(small_rows.size());
-  p->n_narrow = int(narrow_rows.size());
-  p->n_wide = int(wide_rows.size());
+  p->rt->wide_first = int(p->rt->table.size());
+  p->rt->table.insert(p->rt->table.end(), wide_rows.begin(), wide_rows.end());
+  p->rt->n_small = int(small_rows.size());
+  p->rt->n_narrow = int(narrow_rows.size());
+  p->rt->n_wide = int(wide_rows.size());
   return CWT_OK;
 }
 
 // log2 of the row length K of the two-pass factorisation N = R*K
 void set_split(cwt_plan* p) {
   int n_big = 0;
-  for (const auto& g : p->narrow_groups) if (g.logK == 11) n_big += g.count;
-  p->split[0] = p->n_small; p->split[1] = p->n_narrow - n_big; p->split[2] = p->n_wide; p->split[3] = n_big;
+  for (const auto& g : p->rt->narrow_groups) if (g.logK == 11) n_big += g.count;
+  p->split[0] = p->rt->n_small; p->split[1] = p->rt->n_narrow - n_big; p->split[2] = p->rt->n_wide; p->split[3] = n_big;
 }
 
 int chunk_rows_of(const cwt_plan* p) {
@@ -404,7 +414,7 @@ template <typename T> constexpr int default_logp() { return sizeof(T) == 8 ? 13 
 template <typename T>
 bool narrow_ct_all_applies(const cwt_plan* p) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
-  for (const auto& g : p->narrow_groups) {
+  for (const auto& g : p->rt->narrow_groups) {
     if (g.logK == 11 && sizeof(T) == 8 && g.nterms >= 1 && g.nterms <= 4) continue;      // k_narrow_ct_big
     if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 4 || (g.nterms > 1 && g.logK != 10)) return false;
   }
@@ -417,14 +427,14 @@ constexpr int kMaxGridY = 32768;   // rows per launch (gridDim.y is limited to 6
 // K <= 1024 first, then (fp64 only) the K = 2048 groups
 void narrow_class_counts(const cwt_plan* p, int* n_small_k, int* n_big) {
   *n_small_k = *n_big = 0;
-  for (const auto& g : p->narrow_groups) (g.logK == 11 ? *n_big : *n_small_k) += g.count;
+  for (const auto& g : p->rt->narrow_groups) (g.logK == 11 ? *n_big : *n_small_k) += g.count;
 }
 
 template <typename T>
 void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
                           int64_t ncols) {
   constexpr int LOGP = default_logp<T>();
-  const int first = p->narrow_groups.front().first;
+  const int first = p->rt->narrow_groups.front().first;
   int n_small_k, n_big;
   narrow_class_counts(p, &n_small_k, &n_big);
   // complex64 only: rows with K <= 512 (sorted first) on half-size workgroup tiles (store segments stay
@@ -432,17 +442,17 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   int n_half = 0;
   if constexpr (sizeof(T) == 4) {
     if (p->narrow_small && p->logN >= LOGP)
-      for (const auto& g : p->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
+      for (const auto& g : p->rt->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
     for (int r0 = 0; r0 < n_half; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP - 1>), dim3(1u << (p->logN - LOGP + 1), std::min(kMaxGridY, n_half - r0)),
                          dim3(1 << (LOGP - 5)), (size_t(1) << (LOGP - 1)) * sizeof(T), p->stream, xhat,
-                         p->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
+                         p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
                          p->logN, W, long(ldw), long(ncols));
   }
   for (int r0 = n_half; r0 < n_small_k; r0 += kMaxGridY)
     hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_small_k - r0)),
                        dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
-                       p->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
+                       p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
                        p->logN, W, long(ldw), long(ncols));
 }
 
@@ -450,12 +460,12 @@ template <typename T>
 void launch_narrow_ct_big(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
                           int64_t ncols) {
   if constexpr (sizeof(T) == 8) {
-    const int first = p->narrow_groups.front().first;
+    const int first = p->rt->narrow_groups.front().first;
     int n_small_k, n_big;
     narrow_class_counts(p, &n_small_k, &n_big);
     for (int r0 = 0; r0 < n_big; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_big<T>), dim3(1u << (p->logN - 14), std::min(kMaxGridY, n_big - r0)), dim3(1024),
-                         (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rows_dev + first + n_small_k + r0, mo,
+                         (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rt->rows_dev + first + n_small_k + r0, mo,
                          static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
   }
 }
@@ -597,6 +607,7 @@ bool try_pass_b_ct(cwt_plan* p, int logK, const RowDesc* rows, int cnt, cplx<T>*
 template <typename T, int MODE>
 int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int64_t n0, void* out_dev) {
   const int logN = p->logN;
+  if (int rc = check_geometry(p)) return rc;
   const Mother mo{MOTHER_MORLET, 0, 0.0, nullptr};
   cplx<T>* out = static_cast<cplx<T>*>(out_dev);
   if (logN <= 3) {
@@ -656,13 +667,14 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int logN = p->logN;
   const cplx<T>* xhat = static_cast<const cplx<T>*>(xhat_dev);
   cplx<T>* W = static_cast<cplx<T>*>(W_dev);
-  int rc;
-  if (p->n_small) {
+  int rc = check_geometry(p);
+  if (rc) return rc;
+  if (p->rt->n_small) {
     if (logN <= 3) {
       const int total = nrows << logN;
       return timed_launch(p, KC_DIRECT, [&] {
         hipLaunchKernelGGL((k_direct<T, IN_SPECTRUM>), dim3((total + 63) / 64), dim3(64), 0, p->stream,
-                           xhat_dev, p->rows_dev, nrows, mo, logN, 0L, 0L, W, long(ldw), long(ncols));
+                           xhat_dev, p->rt->rows_dev, nrows, mo, logN, 0L, 0L, W, long(ldw), long(ncols));
       });
     }
     // several rows per workgroup: aim at 4096 points (256 threads)
@@ -672,22 +684,22 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     const size_t lds = (size_t(TB) << logN) * sizeof(T);
     return timed_launch(p, KC_SMALL, [&] {
       hipLaunchKernelGGL((k_small<T, IN_SPECTRUM>), dim3((nrows + TB - 1) / TB), dim3(threads), lds,
-                         p->stream, xhat_dev, p->rows_dev, nrows, mo, tw_table<T>(p, logN), logN, logTB,
+                         p->stream, xhat_dev, p->rt->rows_dev, nrows, mo, tw_table<T>(p, logN), logN, logTB,
                          0L, 0L, W, long(ldw), long(ncols));
     });
   }
   const int logP = std::min(p->log_wg_points, logN);
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
-  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && p->n_wide && p->n_narrow;
+  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && p->rt->n_wide && p->rt->n_narrow;
   if (side_narrow) {   // side stream 0 starts after the spectrum exists
     HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
     HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
   }
-  if (p->n_wide) {
+  if (p->rt->n_wide) {
     const int logK = two_pass_logk(p), logR = logN - logK;
-    const int chunk = balanced_chunk(p, p->n_wide);
-    const int nchunks = (p->n_wide + chunk - 1) / chunk;
+    const int chunk = balanced_chunk(p, p->rt->n_wide);
+    const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
     const bool pipelined = p->overlap && nchunks > 1;
     rc = ensure_z(p, pipelined ? 2 * chunk : chunk);
     if (rc) return rc;
@@ -700,8 +712,8 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       HIPCHECK(hipStreamWaitEvent(sb, p->ev_fork, 0));
     }
     for (int c = 0; c < nchunks; ++c) {
-      const int first = c * chunk, cnt = std::min(chunk, p->n_wide - first), buf = pipelined ? (c & 1) : 0;
-      const RowDesc* rows = p->rows_dev + p->wide_first + first;
+      const int first = c * chunk, cnt = std::min(chunk, p->rt->n_wide - first), buf = pipelined ? (c & 1) : 0;
+      const RowDesc* rows = p->rt->rows_dev + p->rt->wide_first + first;
       cplx<T>* Z = static_cast<cplx<T>*>(p->Z) + size_t(buf) * size_t(chunk) * size_t(p->N);
       if (pipelined && c >= 2) HIPCHECK(hipStreamWaitEvent(sa, p->ev_b[buf], 0));   // buffer is free again
       rc = timed_launch(p, KC_PASS_A, [&] {
@@ -727,7 +739,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
   // tails) when "overlap_narrow" is set, else on the plan's own stream
   bool narrow_on_side = false;
-  if (p->n_narrow) {
+  if (p->rt->n_narrow) {
     if (narrow_ct_all_applies<T>(p)) {
       hipStream_t keep = p->stream;
       narrow_on_side = side_narrow;
@@ -741,11 +753,11 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       if (rc) return rc;
       if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
     } else {
-      for (const auto& g : p->narrow_groups) {
+      for (const auto& g : p->rt->narrow_groups) {
         rc = timed_launch(p, KC_NARROW, [&] {
           for (int r0 = 0; r0 < g.count; r0 += kMaxGridY)
             hipLaunchKernelGGL((k_narrow<T>), dim3(1u << (logN - logP), std::min(kMaxGridY, g.count - r0)),
-                               dim3(threads), lds, p->stream, xhat, p->rows_dev + g.first + r0, mo,
+                               dim3(threads), lds, p->stream, xhat, p->rt->rows_dev + g.first + r0, mo,
                                tw_table<T>(p, g.logK), twn_of<T>(p), logN, g.logK, logP - g.logK, W, long(ldw),
                                long(ncols));
         });
@@ -753,9 +765,9 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       }
     }
   }
-  if (p->n_wide) {
-    const int chunk = balanced_chunk(p, p->n_wide);
-    const int nchunks = (p->n_wide + chunk - 1) / chunk;
+  if (p->rt->n_wide) {
+    const int chunk = balanced_chunk(p, p->rt->n_wide);
+    const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
     if (p->overlap && nchunks > 1) {   // join: every pass A is followed by its pass B on side stream 1
       HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
       HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
@@ -838,14 +850,20 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && hipMalloc(reinterpret_cast<void**>(&p->rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
-    rc = fail(CWT_ENOMEM, "row table allocation failed");
+  for (auto& t : p->slots) {
+    if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+      rc = fail(CWT_ENOMEM, "row table allocation failed");
+    if (!rc && hipHostMalloc(reinterpret_cast<void**>(&t.rows_pinned), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+      rc = fail(CWT_ENOMEM, "pinned row table allocation failed");
+    if (!rc && hipEventCreate(&t.uploaded) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  }
   if (!rc && hipMalloc(&p->weights_dev, size_t(max_rows) * sizeof(double)) != hipSuccess)
     rc = fail(CWT_ENOMEM, "weights allocation failed");
-  if (!rc && hipHostMalloc(reinterpret_cast<void**>(&p->rows_pinned), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
-    rc = fail(CWT_ENOMEM, "pinned row table allocation failed");
-  if (!rc && hipHostMalloc(&p->weights_pinned, size_t(max_rows) * sizeof(double)) != hipSuccess)
-    rc = fail(CWT_ENOMEM, "pinned weights allocation failed");
+  for (int i = 0; i < 2; ++i) {
+    if (!rc && hipHostMalloc(&p->weights_pinned[i], size_t(max_rows) * sizeof(double)) != hipSuccess)
+      rc = fail(CWT_ENOMEM, "pinned weights allocation failed");
+    if (!rc && hipEventCreate(&p->weights_ev[i]) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  }
   if (rc) { cwt_plan_destroy(p); return rc; }
   *plan = p;
   return CWT_OK;
@@ -863,10 +881,17 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->rows_dev, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps};
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  if (p->rows_pinned) (void)hipHostFree(p->rows_pinned);
-  if (p->weights_pinned) (void)hipHostFree(p->weights_pinned);
+  for (auto& t : p->slots) {
+    if (t.rows_dev) (void)hipFree(t.rows_dev);
+    if (t.rows_pinned) (void)hipHostFree(t.rows_pinned);
+    if (t.uploaded) (void)hipEventDestroy(t.uploaded);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (p->weights_pinned[i]) (void)hipHostFree(p->weights_pinned[i]);
+    if (p->weights_ev[i]) (void)hipEventDestroy(p->weights_ev[i]);
+  }
   delete p;
   return CWT_OK;
 }
@@ -882,12 +907,13 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   if (!p || !key) return fail(CWT_EINVAL, "plan/key is NULL");
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
-  p->table_valid = false;
-  const int old_lmax = p->loglmax, old_wg = p->log_wg_points;
-  struct Restore {   // a rejected geometry leaves the plan as it was
-    cwt_plan* p; int lmax, wg; bool armed = true;
-    ~Restore() { if (armed && check_geometry(p) != CWT_OK) { p->loglmax = lmax; p->log_wg_points = wg; } }
-  } restore{p, old_lmax, old_wg};
+  for (auto& t : p->slots) t.key.clear();   // the classification depends on the options
+  struct Restore {   // a rejected geometry leaves every geometry-affecting field as it was
+    cwt_plan* p; int lmax, wg, logk, nmax;
+    ~Restore() {
+      if (check_geometry(p) != CWT_OK) { p->loglmax = lmax; p->log_wg_points = wg; p->force_logk = logk; p->narrow_max_logk = nmax; }
+    }
+  } restore{p, p->loglmax, p->log_wg_points, p->force_logk, p->narrow_max_logk};
   if (k == "chunk_rows") { if (value < 0) return fail(CWT_EINVAL, "chunk_rows >= 0"); p->chunk_rows = int(value); }
   else if (k == "narrow") p->narrow = value != 0;
   else if (k == "narrow_max_k") { if (!pow2(value) || value < 16 || value > 4096) return fail(CWT_EINVAL, "narrow_max_k: power of two in [16,4096]"); p->narrow_max_logk = ilog2(value); }
@@ -899,7 +925,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
-  else if (k == "two_pass_logk") p->force_logk = int(value);
+  else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
   else if (k == "narrow_small") p->narrow_small = value != 0;
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
@@ -941,12 +967,14 @@ int cwt_free(int device, void* ptr) {
 }
 int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipSetDevice(p->device));
   HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
   HIPCHECK(hipStreamSynchronize(p->stream));
   return CWT_OK;
 }
 int cwt_memcpy_d2h(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  HIPCHECK(hipSetDevice(p->device));
   HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
   HIPCHECK(hipStreamSynchronize(p->stream));
   return CWT_OK;
@@ -961,13 +989,40 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
 }
 
 namespace {
-// Copies the freshly built row table to the device through the pinned staging buffer.
-int upload_row_table(cwt_plan* p) {
-  HIPCHECK(hipStreamSynchronize(p->stream));  // the staging buffer of the previous call may still be in flight
-  std::memcpy(p->rows_pinned, p->table.data(), p->table.size() * sizeof(RowDesc));
-  HIPCHECK(hipMemcpyAsync(p->rows_dev, p->rows_pinned, p->table.size() * sizeof(RowDesc),
-                          hipMemcpyHostToDevice, p->stream));
+// Makes the slot built from `key` current and returns true, or picks the least recently used slot for a rebuild
+// (returns false; the caller builds p->rt->table and calls upload_row_table).  An empty key never matches.
+bool select_table(cwt_plan* p, const std::vector<double>& key) {
+  ++p->tick;
+  if (!key.empty())
+    for (auto& t : p->slots)
+      if (t.key == key) { p->rt = &t; t.used = p->tick; return true; }
+  cwt_plan::RowTable* lru = &p->slots[0];
+  for (auto& t : p->slots) if (t.used < lru->used) lru = &t;
+  lru->key.clear();
+  lru->used = p->tick;
+  p->rt = lru;
+  return false;
+}
+
+// Copies the freshly built row table of the current slot to the device through the slot's pinned staging buffer and
+// marks the slot as built from `key`.  The only wait is for the slot's previous copy (an event that completed long
+// ago unless rebuilds come back to back); the stream is never synchronised.
+int upload_row_table(cwt_plan* p, const std::vector<double>& key) {
+  cwt_plan::RowTable* t = p->rt;
+  HIPCHECK(hipEventSynchronize(t->uploaded));
+  std::memcpy(t->rows_pinned, t->table.data(), t->table.size() * sizeof(RowDesc));
+  HIPCHECK(hipMemcpyAsync(t->rows_dev, t->rows_pinned, t->table.size() * sizeof(RowDesc), hipMemcpyHostToDevice,
+                          p->stream));
+  HIPCHECK(hipEventRecord(t->uploaded, p->stream));
+  t->key = key;
   return CWT_OK;
+}
+
+std::vector<double> call_key(double kind, std::initializer_list<double> head, std::initializer_list<std::pair<const double*, int>> arrays) {
+  std::vector<double> k{kind};
+  k.insert(k.end(), head.begin(), head.end());
+  for (const auto& a : arrays) k.insert(k.end(), a.first, a.first + a.second);
+  return k;
 }
 }  // namespace
 
@@ -978,11 +1033,8 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  const bool same = p->table_valid && p->last_mother == mother && p->last_param == param &&
-                    p->last_dt == dt && int(p->last_scales.size()) == nrows &&
-                    std::equal(scales, scales + nrows, p->last_scales.begin());
-  if (!same) {
-    p->table_valid = false;
+  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows)}, {{scales, nrows}});
+  if (!select_table(p, key)) {
     double cre, cim;
     int rc = mother_constant(mother, param, &cre, &cim);
     if (rc) return rc;
@@ -996,11 +1048,8 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
       ai[j] = norm * cim;
     }
     rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows);
-    if (!rc) rc = upload_row_table(p);
+    if (!rc) rc = upload_row_table(p, key);
     if (rc) return rc;
-    p->last_mother = mother; p->last_param = param; p->last_dt = dt;
-    p->last_scales.assign(scales, scales + nrows);
-    p->table_valid = true;
   }
   set_split(p);
   Mother mo;
@@ -1019,25 +1068,28 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  p->table_valid = false;
-  double cre, cim;
-  int rc = mother_constant(mother, param, &cre, &cim);
-  if (rc) return rc;
-  const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(p->N) * dt));
   const int total = nbatch * nrows;
-  std::vector<double> a(total), ar(total), ai(total);
-  for (int j = 0; j < total; ++j) {
-    const double s = scales[j % nrows];
-    if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
-    a[j] = s * w1;
-    const double norm = std::sqrt(s * w1 * double(p->N));
-    ar[j] = norm * cre;
-    ai[j] = norm * cim;
+  const std::vector<double> key = call_key(2, {double(mother), param, dt, double(nbatch), double(xhat_ld), double(nrows)},
+                                           {{scales, nrows}});
+  if (!select_table(p, key)) {
+    double cre, cim;
+    int rc = mother_constant(mother, param, &cre, &cim);
+    if (rc) return rc;
+    const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(p->N) * dt));
+    std::vector<double> a(total), ar(total), ai(total);
+    for (int j = 0; j < total; ++j) {
+      const double s = scales[j % nrows];
+      if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
+      a[j] = s * w1;
+      const double norm = std::sqrt(s * w1 * double(p->N));
+      ar[j] = norm * cre;
+      ai[j] = norm * cim;
+    }
+    // W is treated as one (nbatch*nrows) x ldw matrix: row b*nrows + j = scale j of signal b
+    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), xhat_ld, total, nullptr, nullptr, nrows);
+    if (!rc) rc = upload_row_table(p, key);
+    if (rc) return rc;
   }
-  // W is treated as one (nbatch*nrows) x ldw matrix: row b*nrows + j = scale j of signal b
-  rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), xhat_ld, total, nullptr, nullptr, nrows);
-  if (!rc) rc = upload_row_table(p);
-  if (rc) return rc;
   set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
@@ -1051,10 +1103,10 @@ int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* tabl
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  p->table_valid = false;
+  select_table(p, {});                                   // explicit filter banks are not cached
   std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
   int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
-  if (!rc) rc = upload_row_table(p);
+  if (!rc) rc = upload_row_table(p, {});
   if (rc) return rc;
   set_split(p);
   Mother mo;
@@ -1084,12 +1136,15 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (spec_ld != 0 && spec_ld < p->N) return fail(CWT_EINVAL, "spec_ld must be 0 (shared) or >= nfft");
   HIPCHECK(hipSetDevice(p->device));
-  p->table_valid = false;
-  double cre, cim;
-  int rc = mother_constant(mother, param, &cre, &cim);   // validates mother / order only
-  if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
-  if (!rc) rc = upload_row_table(p);
-  if (rc) return rc;
+  const std::vector<double> key = call_key(1, {double(mother), param, double(spec_ld), double(nrows)},
+                                           {{a, nrows}, {amp_re, nrows}, {amp_im, nrows}});
+  if (!select_table(p, key)) {
+    double cre, cim;
+    int rc = mother_constant(mother, param, &cre, &cim);   // validates mother / order only
+    if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
+    if (!rc) rc = upload_row_table(p, key);
+    if (rc) return rc;
+  }
   set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
@@ -1101,12 +1156,16 @@ extern "C++" {
 namespace {
 template <typename T>
 int upload_reals(cwt_plan* p, const double* v, int n) {          // -> p->weights_dev as T[n]
-  HIPCHECK(hipStreamSynchronize(p->stream));
+  // two staging buffers used in turn; the only wait is for the copy that left this buffer two calls ago
+  const int i = p->weights_turn;
+  p->weights_turn ^= 1;
+  HIPCHECK(hipEventSynchronize(p->weights_ev[i]));
   for (int j = 0; j < n; ++j) {
-    if (sizeof(T) == 8) static_cast<double*>(p->weights_pinned)[j] = v[j];
-    else static_cast<float*>(p->weights_pinned)[j] = float(v[j]);
+    if (sizeof(T) == 8) static_cast<double*>(p->weights_pinned[i])[j] = v[j];
+    else static_cast<float*>(p->weights_pinned[i])[j] = float(v[j]);
   }
-  HIPCHECK(hipMemcpyAsync(p->weights_dev, p->weights_pinned, size_t(n) * sizeof(T), hipMemcpyHostToDevice, p->stream));
+  HIPCHECK(hipMemcpyAsync(p->weights_dev, p->weights_pinned[i], size_t(n) * sizeof(T), hipMemcpyHostToDevice, p->stream));
+  HIPCHECK(hipEventRecord(p->weights_ev[i], p->stream));
   return CWT_OK;
 }
 
@@ -1333,12 +1392,12 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
 
 int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
   if (!p || !n) return fail(CWT_EINVAL, "NULL argument");
-  const int total = int(p->table.size());
+  const int total = int(p->rt->table.size());
   *n = total;
   if (!codes) return CWT_OK;
   for (int i = 0; i < total; ++i) {
-    const RowDesc& rd = p->table[i];
-    const int kind = i < p->n_small ? 0 : i < p->wide_first ? (rd.logK == 11 ? 2 : 1) : 3;
+    const RowDesc& rd = p->rt->table[i];
+    const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : 3;
     if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
   }
   return CWT_OK;

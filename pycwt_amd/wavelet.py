@@ -11,6 +11,7 @@ no CPU fallback.
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 
@@ -22,6 +23,7 @@ from .mothers import DOG, MexicanHat, Morlet, Paul
 
 _MOTHERS = {"morlet": Morlet, "paul": Paul, "dog": DOG, "mexicanhat": MexicanHat}
 _plans: dict = {}
+_plans_lock = threading.Lock()
 
 
 def _check_parameter_wavelet(wavelet):
@@ -36,14 +38,30 @@ def _default_precision() -> int:
 
 
 def _plan(nfft: int, precision: int, device: int, rows: int) -> _hip.Plan:
+    """The cached plan of (padded length, precision, device), grown when a call needs more rows.  A plan that is
+    too small is only dropped from the cache, never closed here: a live `DeviceTransform` (or another thread in
+    the middle of a call) may still hold it, and the garbage collector closes it with its last reference.
+    Callers run their whole upload -> transform -> download sequence under `plan.lock`, because the C plan (row
+    table, workspaces, stream) is shared by every thread that asks for the same key; the reference is re-entrant
+    and so is this module, one transform per (length, precision, device) at a time."""
     key = (nfft, precision, device)
-    plan = _plans.get(key)
-    if plan is None or plan.max_rows < rows:
-        if plan is not None:
-            plan.close()
-        plan = _hip.Plan(nfft, precision, max_rows=max(1024, rows), device=device)
-        _plans[key] = plan
-    return plan
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None or plan.max_rows < rows:
+            plan = _hip.Plan(nfft, precision, max_rows=max(1024, rows), device=device)
+            _plans[key] = plan
+        return plan
+
+
+def _reduction_plan(precision: int, device: int, rows: int) -> _hip.Plan:
+    """A plan for the column/row reductions (icwt, power averages): those kernels do not depend on the transform
+    length, so any cached plan of the device and precision with enough rows serves; otherwise the smallest one is
+    made (no FFT tables worth mentioning) instead of a full-length FFT plan."""
+    with _plans_lock:
+        for (nfft, prec, dev), plan in _plans.items():
+            if prec == precision and dev == device and plan.max_rows >= rows and plan.h:
+                return plan
+    return _plan(16, precision, device, rows)
 
 
 def _device_id(mother, strict=True):
@@ -122,11 +140,12 @@ def _cwt_with_host_filter_bank(x, dt, sj, mother, N, precision, device):
     try:
         xd, xh = sc.new(x.size * es), sc.new(N * 2 * es)
         tab, Wd = sc.new(rows * N * 2 * es), sc.new(rows * x.size * 2 * es)
-        xd.upload(plan, x)
-        tab.upload(plan, np.ascontiguousarray(bank, dtype=plan.cplx))
-        plan.forward_fft(xd.ptr, x.size, xh.ptr)
-        plan.transform_rows_table(xh.ptr, tab.ptr, k_lo, nband, Wd.ptr, x.size, x.size)
-        return Wd.download(plan, (rows, x.size), plan.cplx), xh.download(plan, (N,), plan.cplx), keep
+        with plan.lock:
+            xd.upload(plan, x)
+            tab.upload(plan, np.ascontiguousarray(bank, dtype=plan.cplx))
+            plan.forward_fft(xd.ptr, x.size, xh.ptr)
+            plan.transform_rows_table(xh.ptr, tab.ptr, k_lo, nband, Wd.ptr, x.size, x.size)
+            return Wd.download(plan, (rows, x.size), plan.cplx), xh.download(plan, (N,), plan.cplx), keep
     finally:
         sc.free()
 
@@ -196,8 +215,9 @@ class DeviceTransform:
         es = np.dtype(self._plan.real).itemsize
         out = _hip.DeviceBuffer(n * es, self._plan.device)
         try:
-            fill(out.ptr)
-            return out.download(self._plan, (n,), self._plan.real).astype(np.float64)
+            with self._plan.lock:
+                fill(out.ptr)
+                return out.download(self._plan, (n,), self._plan.real).astype(np.float64)
         finally:
             out.free()
 
@@ -241,10 +261,11 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     xd, xh = _hip.DeviceBuffer(n0 * es, device), _hip.DeviceBuffer(N * 2 * es, device)
     Wd = _hip.DeviceBuffer(sj.size * n0 * 2 * es, device)
     try:
-        xd.upload(plan, np.ascontiguousarray(signal, dtype=plan.real))
-        plan.forward_fft(xd.ptr, n0, xh.ptr)
-        plan.transform_rows(xh.ptr, kind, param, dt, sj, Wd.ptr, n0, n0)
-        xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
+        with plan.lock:
+            xd.upload(plan, np.ascontiguousarray(signal, dtype=plan.real))
+            plan.forward_fft(xd.ptr, n0, xh.ptr)
+            plan.transform_rows(xh.ptr, kind, param, dt, sj, Wd.ptr, n0, n0)
+            xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
     except Exception:
         Wd.free()
         raise
@@ -288,11 +309,12 @@ def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
         Wd = sc.new(slab * rows * n0 * 2 * es)
         for b0 in range(0, nb, slab):
             cnt = min(slab, nb - b0)
-            xd.upload(plan, np.ascontiguousarray(X[b0:b0 + cnt], dtype=plan.real))
-            plan.fft_rows(xd.ptr, False, cnt, n0, n0, xh.ptr)
-            plan.transform_rows_batch(xh.ptr, cnt, N, kind, param, dt, sj, Wd.ptr, n0, n0)
-            W[b0:b0 + cnt] = Wd.download(plan, (cnt, rows, n0), plan.cplx)
-            xhat[b0:b0 + cnt] = xh.download(plan, (cnt, N), plan.cplx)
+            with plan.lock:
+                xd.upload(plan, np.ascontiguousarray(X[b0:b0 + cnt], dtype=plan.real))
+                plan.fft_rows(xd.ptr, False, cnt, n0, n0, xh.ptr)
+                plan.transform_rows_batch(xh.ptr, cnt, N, kind, param, dt, sj, Wd.ptr, n0, n0)
+                W[b0:b0 + cnt] = Wd.download(plan, (cnt, rows, n0), plan.cplx)
+                xhat[b0:b0 + cnt] = xh.download(plan, (cnt, N), plan.cplx)
     finally:
         sc.free()
     coi = _coi(mother, n0, dt)
@@ -320,14 +342,15 @@ def icwt(W, sj, dt, dj=1 / 12, wavelet="morlet", *, precision=None, device=0):
     else:
         raise Warning("Input array dimensions do not match.")   # wavelet.py:166
 
-    plan = _plan(_next_pow2(max(b, 2)), precision, device, a)
+    plan = _reduction_plan(precision, device, a)
     esize = np.dtype(plan.real).itemsize
     Wd = _hip.DeviceBuffer(a * b * 2 * esize, device)
     out = _hip.DeviceBuffer(b * esize, device)
     try:
-        Wd.upload(plan, np.ascontiguousarray(W, dtype=plan.cplx))
-        plan.icwt_reduce(Wd.ptr, b, b, row_scale, 1.0, out.ptr)
-        total = out.download(plan, (b,), plan.real).astype(np.float64)
+        with plan.lock:
+            Wd.upload(plan, np.ascontiguousarray(W, dtype=plan.cplx))
+            plan.icwt_reduce(Wd.ptr, b, b, row_scale, 1.0, out.ptr)
+            total = out.download(plan, (b,), plan.real).astype(np.float64)
     finally:
         Wd.free()
         out.free()
@@ -410,8 +433,9 @@ def xwt(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wavelet="mo
             T2 = cwt_device(_normalised(y2, normalize), dt, **kw)
             try:
                 rows, n0 = T1.shape
-                T1._plan.cross_spectrum(T1.device_ptr, T2.device_ptr, rows, n0, n0, T1.device_ptr)
-                W12, freq, coi = T1.W(), T1.freqs, T1.coi
+                with T1._plan.lock:
+                    T1._plan.cross_spectrum(T1.device_ptr, T2.device_ptr, rows, n0, n0, T1.device_ptr)
+                    W12, freq, coi = T1.W(), T1.freqs, T1.coi
             finally:
                 T2.close()
         finally:
@@ -479,26 +503,27 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
     names = iter(range(100))
     alloc = (lambda nbytes: sc.new(nbytes)) if pool is None else (lambda nbytes: sc.named(next(names), nbytes))
     try:
-        xd, xh = alloc(n0 * es), alloc(N * 2 * es)
-        W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
-        for x, W in ((x1, W1), (x2, W2)):
-            xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
-            plan.forward_fft(xd.ptr, n0, xh.ptr)
-            plan.transform_rows(xh.ptr, kind, param, dt, sj, W.ptr, n0, n0)
-        P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
-        plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
-        spec = alloc(rows * N * 2 * es)
-        tmp, S, S12 = W1, W2, alloc(rows * n0 * 2 * es)             # W1/W2 are dead after the products
-        _smooth_on_device(plan, mother, P, rows, n0, dt, dj, sj, spec, tmp, S)
-        _smooth_on_device(plan, mother, Cx, rows, n0, dt, dj, sj, spec, tmp, S12)
-        plan.wct_coherence(S.ptr, S12.ptr, rows, n0, n0, P.ptr)     # result (reals) re-uses P's storage
-        if consume is not None:
-            consume(plan, P, rows, n0)
-            plan.sync()
-            return None, None
-        wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False)
-        awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False) if want_angle else None
-        return wct_, awct
+        with plan.lock:
+            xd, xh = alloc(n0 * es), alloc(N * 2 * es)
+            W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
+            for x, W in ((x1, W1), (x2, W2)):
+                xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
+                plan.forward_fft(xd.ptr, n0, xh.ptr)
+                plan.transform_rows(xh.ptr, kind, param, dt, sj, W.ptr, n0, n0)
+            P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
+            plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
+            spec = alloc(rows * N * 2 * es)
+            tmp, S, S12 = W1, W2, alloc(rows * n0 * 2 * es)             # W1/W2 are dead after the products
+            _smooth_on_device(plan, mother, P, rows, n0, dt, dj, sj, spec, tmp, S)
+            _smooth_on_device(plan, mother, Cx, rows, n0, dt, dj, sj, spec, tmp, S12)
+            plan.wct_coherence(S.ptr, S12.ptr, rows, n0, n0, P.ptr)     # result (reals) re-uses P's storage
+            if consume is not None:
+                consume(plan, P, rows, n0)
+                plan.sync()
+                return None, None
+            wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False)
+            awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False) if want_angle else None
+            return wct_, awct
     finally:
         if pool is None:
             sc.free()

@@ -209,3 +209,28 @@ def test_phase_stamps_are_recorded_per_workgroup(emu_library):
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, np.array([3.0, 9.0]), orc.Mother(orc.MORLET, 6)))
     assert per_row.max() < 1e-12
     plan.close()
+
+
+def test_row_table_cache_two_slots(emu_library):
+    """The plan keeps the two most recent classified row tables (no rebuild / upload / host sync when calls alternate
+    between two fixed argument sets, as the coherence pipeline does): hits, misses and evictions must all give the
+    rows of the arguments actually passed."""
+    N = 1 << 13
+    x = np.random.default_rng(3).standard_normal(N)
+    m = orc.Mother(orc.MORLET, 6)
+    grids = {"A": np.array([2.0, 30.0, 500.0]), "B": np.array([3.0, 9.0, 81.0, 700.0]), "C": np.array([5.0, 6.0])}
+    refs = {k: orc.cwt_rows(x, 1.0, v, m) for k, v in grids.items()}
+    plan = _hip.Plan(N, 64, max_rows=8, lib=emu_library)
+    for name in "ABABCACBBA":
+        W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, grids[name], want_xhat=False)
+        per_row, _ = row_errors(W, refs[name])
+        assert per_row.max() < 1e-12, name
+    W, _ = plan.execute_host(x, orc.DOG, 2, 1.0, grids["A"], want_xhat=False)      # same scales, other mother: a miss
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, grids["A"], orc.Mother(orc.DOG, 2)))
+    assert per_row.max() < 1e-12
+    plan.set_option("narrow", 0)                                                    # options invalidate both slots
+    W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, grids["A"], want_xhat=False)
+    assert plan.last_split()["narrow"] == 0
+    per_row, _ = row_errors(W, refs["A"])
+    assert per_row.max() < 1e-12
+    plan.close()

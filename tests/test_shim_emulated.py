@@ -6,6 +6,7 @@ import pytest
 
 import pycwt_amd
 from conftest import load_golden, row_errors
+from oracle import cwt_oracle as orc
 
 
 def check_tuple(out, g, tol=1e-12):
@@ -180,3 +181,50 @@ def test_device_resident_transform_and_reductions(emulated):
     np.testing.assert_allclose(T.sj, g["sj"])
     np.testing.assert_allclose(T.coi, g["coi"])
     T.close()
+
+
+def test_plan_cache_growth_keeps_live_transforms_valid(emulated):
+    """A later call that needs more rows replaces the cached plan; a DeviceTransform made before must keep working
+    (its plan is dropped from the cache, not destroyed)."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(300)
+    T = pycwt_amd.cwt_device(x, 0.5, 0.5, -1, -1, "morlet")
+    before = T.global_power()
+    pycwt_amd.cwt_batch(rng.standard_normal((90, 300)), 0.5, 0.25, -1, -1, "morlet")   # 90 x 29 rows > 1024
+    np.testing.assert_array_equal(T.global_power(), before)
+    W = T.W()
+    ref = orc.cwt(x, 0.5, 0.5, -1, -1, "morlet")[0]
+    assert np.abs(W - ref).max() < 1e-12 * np.abs(ref).max()
+    T.close()
+
+
+def test_threads_sharing_a_cached_plan_get_the_serial_results(emulated):
+    """pycwt.cwt is re-entrant; here every (length, precision, device) has ONE cached C plan, so concurrent callers
+    are serialised on its lock.  Eight threads, two signal lengths, different scale grids: every result must equal
+    the one computed alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(8)
+    jobs = [(rng.standard_normal(n), dj, w) for n in (500, 4000) for dj in (0.5, 0.25)
+            for w in ("morlet", "dog")]
+    serial = [pycwt_amd.cwt(x, 1.0, dj, -1, -1, w)[0] for x, dj, w in jobs]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        par = list(ex.map(lambda j: pycwt_amd.cwt(j[0], 1.0, j[1], -1, -1, j[2])[0], jobs * 3))
+    for i, W in enumerate(par):
+        np.testing.assert_array_equal(W, serial[i % len(jobs)])
+
+
+def test_rejected_option_leaves_the_plan_usable(emulated):
+    from pycwt_amd import _hip
+    N = 1 << 13
+    x = np.random.default_rng(2).standard_normal(N)
+    sj = np.array([2.0, 20.0, 700.0])
+    plan = _hip.Plan(N, 64, max_rows=4, lib=emulated)
+    ref = orc.cwt_rows(x, 1.0, sj, orc.Mother(orc.MORLET, 6))
+    W0, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj)
+    for key, val in (("two_pass_logk", 1), ("two_pass_logk", 99), ("wg_points", 7), ("lmax", 8)):
+        with pytest.raises(_hip.HipError):
+            plan.set_option(key, val)
+        W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj)
+        np.testing.assert_array_equal(W, W0)
+    assert np.abs(W0 - ref).max() < 1e-12 * np.abs(ref).max()
+    plan.close()
