@@ -4,10 +4,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cwt_hip.h"
@@ -47,6 +52,84 @@ int ilog2(int64_t v) {
 }
 
 struct Timed { int cls; hipEvent_t a, b; };
+
+// Device -> pageable host copies of results (the W matrix of the drop-in call is GiBs of fresh NumPy memory).  One
+// hipMemcpyAsync into pageable memory runs at ~12 GB/s on this platform (single staging thread + first-touch page
+// faults); page-locking the caller's array costs more than it saves.  Here the copy is cut into chunks that the DMA
+// engine writes into a ring of page-locked slots (allocated once per plan) while a few worker threads memcpy the
+// previous chunks into the caller's memory, each thread touching its own pages.
+struct HostCopier {
+  static constexpr int kSlots = 3;
+  static constexpr size_t kChunk = size_t(32) << 20;
+  int kThreads = 8;   // worker threads: CWT_COPY_THREADS, default min(32, cores / 2) -- first-touch page faults of the
+                      // destination dominate, and they scale with the number of threads touching distinct pages
+  void* slot[kSlots] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr};
+  struct Task { char* dst; const char* src; size_t n; int slot; };
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::deque<Task> q;
+  int pending[kSlots] = {0, 0, 0};
+  bool stop = false;
+
+  bool ready() const { return slot[0] != nullptr; }
+  int init() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    kThreads = int(std::max(1u, std::min(32u, hc / 2)));
+    if (const char* e = std::getenv("CWT_COPY_THREADS")) kThreads = std::max(1, std::min(256, std::atoi(e)));
+    for (int i = 0; i < kSlots; ++i) {
+      if (hipHostMalloc(&slot[i], kChunk) != hipSuccess || hipEventCreate(&ev[i]) != hipSuccess) return -1;
+    }
+    for (int t = 0; t < kThreads; ++t) workers.emplace_back([this] { run(); });
+    return 0;
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [this] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        t = q.front();
+        q.pop_front();
+      }
+      std::memcpy(t.dst, t.src, t.n);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending[t.slot] == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void wait_slot(int i) {
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [this, i] { return pending[i] == 0; });
+  }
+  // hands the `n` bytes that sit in slot i to the workers, in kThreads pieces
+  void scatter(int i, char* dst, size_t n) {
+    const size_t piece = ((n + kThreads - 1) / kThreads + 4095) & ~size_t(4095);
+    std::lock_guard<std::mutex> lk(m);
+    for (size_t off = 0; off < n; off += piece) {
+      q.push_back({dst + off, static_cast<const char*>(slot[i]) + off, std::min(piece, n - off), i});
+      ++pending[i];
+    }
+    cv_work.notify_all();
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& w : workers) w.join();
+    workers.clear();
+    for (int i = 0; i < kSlots; ++i) {
+      if (slot[i]) (void)hipHostFree(slot[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      slot[i] = nullptr; ev[i] = nullptr;
+    }
+  }
+};
 
 }  // namespace
 
@@ -113,6 +196,7 @@ struct cwt_plan {
   RowTable* rt = &slots[0];
   uint64_t tick = 0;
   int split[4] = {0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024, two-pass, band-limited K = 2048
+  HostCopier* copier = nullptr;       // created by the first large device -> host copy
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
@@ -800,6 +884,51 @@ int set_func_attrs() {
   return CWT_OK;
 }
 
+// Device -> host copy on the plan's stream, synchronous.  Small copies go straight through hipMemcpyAsync; large ones
+// through the pinned ring of HostCopier (see there).
+int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
+  if (bytes < HostCopier::kChunk + HostCopier::kChunk / 2) {
+    HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
+    HIPCHECK(hipStreamSynchronize(p->stream));
+    return CWT_OK;
+  }
+  if (!p->copier) {
+    p->copier = new HostCopier();
+    if (p->copier->init() != 0) {
+      (void)hipGetLastError();
+      p->copier->shutdown();
+      delete p->copier;
+      p->copier = nullptr;
+      HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));   // no pinned memory left
+      HIPCHECK(hipStreamSynchronize(p->stream));
+      return CWT_OK;
+    }
+  }
+  HostCopier* c = p->copier;
+  const size_t chunk = HostCopier::kChunk;
+  const size_t nchunks = (bytes + chunk - 1) / chunk;
+  char* dst = static_cast<char*>(dst_host);
+  const char* src = static_cast<const char*>(src_dev);
+  hipError_t err = hipSuccess;
+  for (size_t i = 0; i <= nchunks && err == hipSuccess; ++i) {
+    if (i < nchunks) {                                   // DMA of chunk i into its slot (after the slot's last scatter)
+      const int sl = int(i % HostCopier::kSlots);
+      c->wait_slot(sl);
+      const size_t n = std::min(chunk, bytes - i * chunk);
+      err = hipMemcpyAsync(c->slot[sl], src + i * chunk, n, hipMemcpyDeviceToHost, p->stream);
+      if (err == hipSuccess) err = hipEventRecord(c->ev[sl], p->stream);
+    }
+    if (i > 0 && err == hipSuccess) {                    // chunk i-1 has landed: hand it to the workers
+      const int sl = int((i - 1) % HostCopier::kSlots);
+      err = hipEventSynchronize(c->ev[sl]);
+      if (err == hipSuccess) c->scatter(sl, dst + (i - 1) * chunk, std::min(chunk, bytes - (i - 1) * chunk));
+    }
+  }
+  for (int sl = 0; sl < HostCopier::kSlots; ++sl) c->wait_slot(sl);
+  if (err != hipSuccess) { (void)hipStreamSynchronize(p->stream); return fail(CWT_EHIP, std::string("device -> host copy: ") + hipGetErrorString(err)); }
+  return CWT_OK;
+}
+
 int grow(void** buf, size_t* have, size_t need, hipStream_t s) {
   if (*have >= need) return CWT_OK;
   if (*buf) { HIPCHECK(hipStreamSynchronize(s)); HIPCHECK(hipFree(*buf)); *buf = nullptr; *have = 0; }
@@ -879,6 +1008,7 @@ int cwt_plan_destroy(cwt_plan* p) {
     if (p->ev_b[i]) (void)hipEventDestroy(p->ev_b[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
   void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps};
@@ -975,9 +1105,7 @@ int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
 int cwt_memcpy_d2h(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipSetDevice(p->device));
-  HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
-  HIPCHECK(hipStreamSynchronize(p->stream));
-  return CWT_OK;
+  return copy_d2h(p, dst, src, bytes);
 }
 
 int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
@@ -1354,10 +1482,10 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (W_host) {
     rc = cwt_transform_rows(p, p->hxhat, mother, param, dt, scales, nrows, p->hW, n0, n0);
     if (rc) return rc;
-    HIPCHECK(hipMemcpyAsync(W_host, p->hW, size_t(nrows) * size_t(n0) * 2 * es, hipMemcpyDeviceToHost, p->stream));
   }
   if (xhat_host)
     HIPCHECK(hipMemcpyAsync(xhat_host, p->hxhat, size_t(p->N) * 2 * es, hipMemcpyDeviceToHost, p->stream));
+  if (W_host) return copy_d2h(p, W_host, p->hW, size_t(nrows) * size_t(n0) * 2 * es);
   HIPCHECK(hipStreamSynchronize(p->stream));
   return CWT_OK;
 }

@@ -29,11 +29,12 @@ def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
 class HipEngine:
     """Runs the hot path on this rank's GPU through libcwt_hip.so on torch's current stream."""
 
-    def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int):
+    def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int, on_torch_stream: bool = True):
         import torch
         self.torch = torch
         self.plan = _hip.Plan(nfft, precision, max_rows=max_rows, device=device_index)
-        self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
+        if on_torch_stream:               # tensors that live on a GPU: queue behind torch's work on its stream
+            self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
 
     def forward(self, x, n0, xhat):
         """x: (n0,) or (batch, n0) reals -> xhat: (N,) or (batch, N) spectra."""
@@ -100,7 +101,7 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     kind, param = _device_id(mother)
     nbatch = shape[0] if len(shape) == 2 else 1
     if engine is None:
-        engine = HipEngine(N, precision, max(1, mine.size * nbatch), device.index or 0)
+        engine = HipEngine(N, precision, max(1, mine.size * nbatch), device.index or 0, device.type == "cuda")
     xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
     engine.forward(x, n0, xhat)
@@ -126,7 +127,7 @@ def icwt_sharded(W_local, sj_local, dt, dj=1 / 12, wavelet="morlet", *, group=No
         if engine is None:
             n = W_local.shape[1]
             engine = HipEngine(_next_pow2(max(n, 2)), 64 if real_t == torch.float64 else 32, W_local.shape[0],
-                               W_local.device.index or 0)
+                               W_local.device.index or 0, W_local.device.type == "cuda")
         engine.icwt_partial(W_local, np.ascontiguousarray(sj_local, dtype=np.float64), part)
     if world > 1:
         dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM, group=group)

@@ -1,8 +1,9 @@
 """Multi-process path of pycwt_amd.parallel under the gloo backend (world_size 2, CPU).
 
 The collective logic (one broadcast of the signal, interleaved row shards, one reduce for icwt) is
-exercised for real; the per-rank compute engine is a CPU stand-in built on the oracle, injected
-through the `engine=` test hook (the product default is the HIP engine)."""
+exercised for real.  The per-rank compute engine is the product's HipEngine -> C ABI with the library swapped for the
+CPU emulation of the real kernels (tests/emu), and, in one test, a stand-in built on the oracle injected through the
+`engine=` hook to check the call pattern."""
 import os
 import socket
 import sys
@@ -81,6 +82,53 @@ def test_two_ranks_shard_broadcast_and_reduce(tmp_path):
         np.testing.assert_allclose(r["coi"], coi)
     np.testing.assert_allclose(r0["iw"], orc.icwt(W, sj, 0.3, 1 / 6, "paul"), rtol=1e-11, atol=1e-13)
     assert r1["iw"].size == 0
+
+
+def _kernel_worker(rank, world, port, tmpdir):
+    """cwt_sharded / icwt_sharded with the DEFAULT engine (HipEngine -> C ABI), the library being the CPU emulation of
+    the real kernels: C-ABI plumbing, broadcast and sharding run together on 2 ranks, for one signal and a batch."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import build_emu
+    from pycwt_amd import _hip, parallel
+    _hip._default = _hip.Library(build_emu.build())      # test infrastructure: kernels on the CPU emulation
+    cpu = torch.device("cpu")
+    x = np.random.default_rng(6).standard_normal(5000) if rank == 0 else None
+    W, mine, sj, freqs, coi = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu)
+    iw = parallel.icwt_sharded(W, sj[mine], 0.5, 1 / 4, "morlet")
+    X = np.random.default_rng(7).standard_normal((3, 700)) if rank == 0 else None
+    Wb, mineb, sjb, _, _ = parallel.cwt_sharded(X, 1.0, 1 / 2, -1, -1, "dog", device=cpu, precision=32)
+    np.savez(os.path.join(tmpdir, f"k{rank}.npz"), W=W.numpy(), mine=mine, sj=sj, iw=np.zeros(0) if iw is None else iw,
+             Wb=Wb.numpy(), mineb=mineb, sjb=sjb)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_real_kernels_through_the_c_abi(tmp_path):
+    from oracle import cwt_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()                                     # build once, before the workers race for it
+    port = _free_port()
+    mp.spawn(_kernel_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"k{i}.npz") for i in range(2)]
+    x = np.random.default_rng(6).standard_normal(5000)
+    W, sj, *_ = orc.cwt(x, 0.5, 1 / 4, -1, -1, "morlet")
+    full = np.empty_like(W)
+    for q in r:
+        full[q["mine"]] = q["W"]
+    assert np.abs(full - W).max() < 1e-12 * np.abs(W).max()
+    np.testing.assert_allclose(r[0]["iw"], orc.icwt(W, sj, 0.5, 1 / 4, "morlet"), rtol=1e-10, atol=1e-12)
+    X = np.random.default_rng(7).standard_normal((3, 700))
+    for b in range(3):
+        Wr, sjr, *_ = orc.cwt(X[b].astype(np.float32), 1.0, 1 / 2, -1, -1, "dog")
+        got = np.empty_like(Wr)
+        for q in r:
+            got[q["mineb"]] = q["Wb"][b]
+        assert np.abs(got - Wr).max() < 3e-5 * np.abs(Wr).max()
 
 
 def _mc_worker(rank, world, port, tmpdir):
