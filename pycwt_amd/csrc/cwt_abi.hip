@@ -929,6 +929,18 @@ int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
   return CWT_OK;
 }
 
+// Side streams carry filler work (band-limited rows beside the two-pass chain): lowest priority, so that their
+// workgroups take the slots the chain leaves free (launch ramps and tails) instead of competing with it.
+// CWT_SIDE_PRIORITY=0 creates them at default priority (tuning).
+hipError_t create_side_stream(hipStream_t* s) {
+  int least = 0, greatest = 0;
+  const char* e = std::getenv("CWT_SIDE_PRIORITY");
+  if ((!e || std::atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+  (void)hipGetLastError();
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 int grow(void** buf, size_t* have, size_t need, hipStream_t s) {
   if (*have >= need) return CWT_OK;
   if (*buf) { HIPCHECK(hipStreamSynchronize(s)); HIPCHECK(hipFree(*buf)); *buf = nullptr; *have = 0; }
@@ -974,7 +986,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
-    if (hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking) != hipSuccess ||
+    if (create_side_stream(&p->side[i]) != hipSuccess ||
         hipEventCreate(&p->ev_a[i]) != hipSuccess || hipEventCreate(&p->ev_b[i]) != hipSuccess)
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
