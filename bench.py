@@ -200,9 +200,10 @@ class Workload:
         plan.set_option("profile", 0)
         plan.set_option("overlap", self.opts.get("overlap", 0))
         split = plan.last_split()
-        units_by_class = {"small": split["small"] * N, "narrow": (split["narrow"] - split["narrow_k2048"]) * N,
-                          "narrow_big": split["narrow_k2048"] * N, "pass_a": split["two_pass"] * N,
-                          "pass_b": split["two_pass"] * N}
+        units_by_class = {"small": split["small"] * N,
+                          "narrow": (split["narrow"] - split["narrow_k2048"] - split["narrow_many"]) * N,
+                          "narrow_big": split["narrow_k2048"] * N, "narrow_many": split["narrow_many"] * N,
+                          "pass_a": split["two_pass"] * N, "pass_b": split["two_pass"] * N}
         kern = {name: {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
                 for name, (ms, cnt) in tm.items()}
         cand = [k for k in kern if units_by_class.get(k)]

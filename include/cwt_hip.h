@@ -69,7 +69,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "narrow_max_k" largest per-row transform length of that path (power of two)
  *   "lmax"         largest single-workgroup FFT length (power of two, <= 4096)
  *   "wg_points"    complex points per workgroup of the fused kernels
- *   "narrow_terms" largest number of aliased bins per FFT input of that path (1 = off)
+ *   "narrow_terms" largest number of aliased bins per FFT input of that path at K = 1024 (1 = off, <= 16)
+ *   "big_terms"    the same at K = 2048 (fp64, 16384-point workgroups; <= 8)
  *   "overlap"      1 = run pass A of chunk c+1 beside pass B of chunk c on side
  *                  streams; 0 (default) = strictly one after the other
  *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
@@ -228,9 +229,10 @@ int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
  * since the last call in *n_records and starts over.  Synchronises the stream.                                       */
 int cwt_plan_read_stamps(cwt_plan* plan, uint64_t* out_host, int64_t cap_records, int64_t* n_records);
 /* How the last cwt_transform_rows call split its rows: counts[0] = rows done by the single-workgroup
- * kernel, [1] = band-limited single pass with K <= 1024, [2] = two-pass, [3] = band-limited single pass
- * with K = 2048 (fp64, 16384-point workgroups). */
-int cwt_plan_last_split(cwt_plan* plan, int counts[4]);
+ * kernel, [1] = band-limited single pass with K <= 1024 and at most 4 aliased terms, [2] = two-pass, [3] = band-limited
+ * single pass with K = 2048 (fp64, 16384-point workgroups), [4] = band-limited single pass with K = 1024 and 5..16
+ * aliased terms. */
+int cwt_plan_last_split(cwt_plan* plan, int counts[5]);
 
 #ifdef __cplusplus
 }

@@ -310,9 +310,9 @@ class Plan:
 
     @_locked
     def last_split(self):
-        c = (C.c_int * 4)()
+        c = (C.c_int * 5)()
         self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
-        return {"small": c[0], "narrow": c[1] + c[3], "two_pass": c[2], "narrow_k2048": c[3]}
+        return {"small": c[0], "narrow": c[1] + c[3] + c[4], "two_pass": c[2], "narrow_k2048": c[3], "narrow_many": c[4]}
 
 
 class DeviceBuffer:

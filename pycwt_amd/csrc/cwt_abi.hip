@@ -40,10 +40,10 @@ int fail(int code, const std::string& msg) {
       return fail(CWT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
-enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_BIG, KC_PASS_A,
-                   KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_COUNT };
-const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a", "fwd_pass_b", "small",  "direct", "narrow",
-                                           "narrow_big", "pass_a",    "pass_b",     "icwt",   "elementwise"};
+enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_MANY, KC_NARROW_BIG,
+                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_COUNT };
+const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a",  "fwd_pass_b", "small",  "direct", "narrow",
+                                           "narrow_many", "narrow_big", "pass_a",     "pass_b", "icwt",   "elementwise"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -149,7 +149,8 @@ struct cwt_plan {
   int log_wg_points = 13;
   int profile = 0;
   int use_ct = 1;          // compile-time specialised kernels where the geometry matches
-  int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input (K = 1024)
+  int narrow_terms = 4;    // band-limited path: up to this many aliased bins per FFT input at K = 1024 (<= 16)
+  int big_terms = 6;       // ... and at K = 2048 (fp64, 16384-point workgroups; <= 8)
   int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
@@ -195,7 +196,8 @@ struct cwt_plan {
   RowTable slots[2];
   RowTable* rt = &slots[0];
   uint64_t tick = 0;
-  int split[4] = {0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024, two-pass, band-limited K = 2048
+  int split[5] = {0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
+                                    // band-limited K = 2048, band-limited K = 1024 with 5..16 terms
   HostCopier* copier = nullptr;       // created by the first large device -> host copy
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
@@ -394,17 +396,24 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       small_rows.push_back(rd);
     } else {
       const int need = std::max(4, ilog2(std::max(rd.nband, 1)));
+      // Support wider than 1024 bins: several aliased terms per FFT input, at K = 1024 (8192-point tiles) or, fp64
+      // only, K = 2048 (16384-point tiles, one workgroup per CU).  Measured us per row at N = 2^20 (tools/
+      // terms_sweep.py; two-pass: 9.1 fp64, 5.0 fp32): fp64 K = 1024: 4.3 / 4.9 / 6.1 / 7.2 / 8.5 for 2 / 3 / 4 / 6 / 8
+      // terms, K = 2048: 5.0 / 5.5 / 6.2 / 6.8 / 7.6 / 8.2 / 9.4 for 1 / 2 / 3 / 4 / 5 / 6 / 8; fp32 K = 1024: 2.9 /
+      // 3.2 / 3.5 / 4.3 / 4.8 / 5.3 for 2 / 3 / 4 / 6 / 8 / 10.  Hence: K = 1024 up to 3 terms, K = 2048 beyond.
+      const int t1 = (rd.nband + 1023) >> 10, t2 = (rd.nband + 2047) >> 11;
+      const bool k1_ok = p->narrow && multi_ok && t1 <= p->narrow_terms;
+      const bool k2_ok = p->narrow && big_ok && t2 <= p->big_terms;
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
-      } else if (p->narrow && big_ok && rd.nband <= (p->narrow_terms << 11) &&
-                 (rd.nband <= 2048 || rd.nband > (p->narrow_terms << 10))) {
-        rd.logK = 11;                                   // K = 2048, 16384-point workgroups (k_narrow_ct_big)
-        rd.nterms = (rd.nband + 2047) >> 11;
+      } else if (k1_ok && (!k2_ok || t1 <= 3)) {
+        rd.logK = 10;                                   // k_narrow_ct_all (<= 4 terms) / k_narrow_ct_many
+        rd.nterms = t1;
         narrow_rows.push_back(rd);
-      } else if (p->narrow && multi_ok && rd.nband <= (p->narrow_terms << 10)) {
-        rd.logK = 10;                                   // several aliased bins per input (k_narrow_ct)
-        rd.nterms = (rd.nband + 1023) >> 10;
+      } else if (k2_ok) {
+        rd.logK = 11;                                   // k_narrow_ct_big
+        rd.nterms = t2;
         narrow_rows.push_back(rd);
       } else {
         // pass A class: how many bins k1 of a column can be non-zero (see pass_a_band_body)
@@ -415,7 +424,12 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       }
     }
   }
-  auto group_key = [](const RowDesc& x) { return (x.logK == 11 ? 1000 : 0) + x.logK + 100 * x.nterms; };
+  // launch classes, in table order: 0 = k_narrow_ct_all (K <= 1024, <= 4 terms), 1 = k_narrow_ct_many (K = 1024,
+  // 5..16 terms), 2 = k_narrow_ct_big (K = 2048)
+  auto group_key = [](const RowDesc& x) {
+    const int cls = x.logK == 11 ? 2 : (x.nterms > 4 ? 1 : 0);
+    return cls * 100000 + x.logK + 100 * x.nterms;
+  };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
   p->rt->table.clear();
@@ -439,9 +453,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
 
 // log2 of the row length K of the two-pass factorisation N = R*K
 void set_split(cwt_plan* p) {
-  int n_big = 0;
-  for (const auto& g : p->rt->narrow_groups) if (g.logK == 11) n_big += g.count;
-  p->split[0] = p->rt->n_small; p->split[1] = p->rt->n_narrow - n_big; p->split[2] = p->rt->n_wide; p->split[3] = n_big;
+  int n_big = 0, n_many = 0;
+  for (const auto& g : p->rt->narrow_groups) {
+    if (g.logK == 11) n_big += g.count;
+    else if (g.nterms > 4) n_many += g.count;
+  }
+  p->split[0] = p->rt->n_small; p->split[1] = p->rt->n_narrow - n_big - n_many; p->split[2] = p->rt->n_wide;
+  p->split[3] = n_big; p->split[4] = n_many;
 }
 
 int chunk_rows_of(const cwt_plan* p) {
@@ -499,8 +517,8 @@ template <typename T>
 bool narrow_ct_all_applies(const cwt_plan* p) {
   if (!p->use_ct || std::min(p->log_wg_points, p->logN) != default_logp<T>()) return false;
   for (const auto& g : p->rt->narrow_groups) {
-    if (g.logK == 11 && sizeof(T) == 8 && g.nterms >= 1 && g.nterms <= 4) continue;      // k_narrow_ct_big
-    if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 4 || (g.nterms > 1 && g.logK != 10)) return false;
+    if (g.logK == 11 && sizeof(T) == 8 && g.nterms >= 1 && g.nterms <= 8) continue;      // k_narrow_ct_big
+    if (g.logK < 4 || g.logK > 10 || g.nterms < 1 || g.nterms > 16 || (g.nterms > 1 && g.logK != 10)) return false;
   }
   return true;
 }
@@ -509,9 +527,25 @@ constexpr int kMaxGridY = 32768;   // rows per launch (gridDim.y is limited to 6
 
 // rows of the two compile-time band-limited kernels: the row table is sorted by class, groups with
 // K <= 1024 first, then (fp64 only) the K = 2048 groups
-void narrow_class_counts(const cwt_plan* p, int* n_small_k, int* n_big) {
+void narrow_class_counts(const cwt_plan* p, int* n_small_k, int* n_big, int* n_many = nullptr) {
+  int many = 0;
   *n_small_k = *n_big = 0;
-  for (const auto& g : p->rt->narrow_groups) (g.logK == 11 ? *n_big : *n_small_k) += g.count;
+  for (const auto& g : p->rt->narrow_groups) (g.logK == 11 ? *n_big : g.nterms > 4 ? many : *n_small_k) += g.count;
+  if (n_many) *n_many = many;
+}
+
+template <typename T>
+void launch_narrow_ct_many(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw,
+                           int64_t ncols) {
+  constexpr int LOGP = default_logp<T>();
+  const int first = p->rt->narrow_groups.front().first;
+  int n_small_k, n_big, n_many;
+  narrow_class_counts(p, &n_small_k, &n_big, &n_many);
+  for (int r0 = 0; r0 < n_many; r0 += kMaxGridY)
+    hipLaunchKernelGGL((k_narrow_ct_many<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_many - r0)),
+                       dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
+                       p->rt->rows_dev + first + n_small_k + r0, mo, static_cast<const cplx<T>*>(p->tw_all),
+                       twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
 }
 
 template <typename T>
@@ -545,11 +579,11 @@ void launch_narrow_ct_big(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
                           int64_t ncols) {
   if constexpr (sizeof(T) == 8) {
     const int first = p->rt->narrow_groups.front().first;
-    int n_small_k, n_big;
-    narrow_class_counts(p, &n_small_k, &n_big);
+    int n_small_k, n_big, n_many;
+    narrow_class_counts(p, &n_small_k, &n_big, &n_many);
     for (int r0 = 0; r0 < n_big; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_big<T>), dim3(1u << (p->logN - 14), std::min(kMaxGridY, n_big - r0)), dim3(1024),
-                         (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rt->rows_dev + first + n_small_k + r0, mo,
+                         (size_t(1) << 14) * sizeof(T), p->stream, xhat, p->rt->rows_dev + first + n_small_k + n_many + r0, mo,
                          static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
   }
 }
@@ -828,10 +862,11 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       hipStream_t keep = p->stream;
       narrow_on_side = side_narrow;
       if (narrow_on_side) p->stream = p->side[0];
-      int n_small_k, n_big;
-      narrow_class_counts(p, &n_small_k, &n_big);
+      int n_small_k, n_big, n_many;
+      narrow_class_counts(p, &n_small_k, &n_big, &n_many);
       rc = CWT_OK;
       if (n_small_k) rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      if (!rc && n_many) rc = timed_launch(p, KC_NARROW_MANY, [&] { launch_narrow_ct_many<T>(p, xhat, mo, W, ldw, ncols); });
       if (!rc && n_big) rc = timed_launch(p, KC_NARROW_BIG, [&] { launch_narrow_ct_big<T>(p, xhat, mo, W, ldw, ncols); });
       p->stream = keep;
       if (rc) return rc;
@@ -983,6 +1018,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->prec = precision;
   p->max_rows = max_rows;
   p->log_wg_points = precision == 64 ? 13 : 14;
+  p->narrow_terms = precision == 64 ? 4 : 8;      // see the cost table in build_row_table
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
@@ -1085,7 +1121,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
       p->stamp_cap = value;
     }
   }
-  else if (k == "narrow_terms") { if (value < 1 || value > 4) return fail(CWT_EINVAL, "narrow_terms in [1,4]"); p->narrow_terms = int(value); }
+  else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
+  else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);
 }
@@ -1554,9 +1591,9 @@ int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, i
   return CWT_OK;
 }
 
-int cwt_plan_last_split(cwt_plan* p, int counts[4]) {
+int cwt_plan_last_split(cwt_plan* p, int counts[5]) {
   if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
-  for (int i = 0; i < 4; ++i) counts[i] = p->split[i];
+  for (int i = 0; i < 5; ++i) counts[i] = p->split[i];
   return CWT_OK;
 }
 

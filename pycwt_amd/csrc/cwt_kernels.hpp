@@ -490,6 +490,44 @@ __device__ __forceinline__ unsigned pass_a_tile() {
   return ((2 * sizeof(T)) << LOGTQ) == 64 ? xcd_tile_any() : blockIdx.x;
 }
 
+// Phase PH of NQ of the multi-term input stage of narrow_ct_body (see there): the Y tiles of all NTERMS terms for the
+// FFT inputs q in [PH K/NQ, (PH+1) K/NQ) go to LDS, the thread's slots e in [PH 16/NQ, (PH+1) 16/NQ) are finished.
+// Compile-time recursion over PH keeps every register-array index a constant.
+template <typename T, int LOGK, int LOGP, int NTERMS, int NQ, int PH>
+__device__ __forceinline__ void narrow_phases(const cplx<T>* __restrict__ xhat, const RowDesc& rd, const Mother& mo,
+                                              int N, cplx<T>* ytile, int j, const cplx<T>& rho, const cplx<T>& step,
+                                              const cplx<T>& stepw, cplx<T>& cur, int& d, T (&re)[16], T (&im)[16]) {
+  constexpr int K = 1 << LOGK, NT = K >> 4, KQ = K / NQ, EQ = 16 / NQ;
+  if constexpr (PH > 0) __syncthreads();                   // every thread is done reading the previous phase
+  for (int idx = threadIdx.x; idx < NTERMS * KQ; idx += (1 << (LOGP - 4))) {
+    const int i = idx / KQ, q = PH * KQ + (idx - i * KQ);
+    const int dq = (q - rd.k_lo) & (K - 1);
+    ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + dq + (i << LOGK), N - 1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int el = 0; el < EQ; ++el) {
+    constexpr int E0 = PH * EQ;
+    cplx<T> h = ytile[(NTERMS - 1) * KQ + j + el * NT];
+#pragma unroll
+    for (int i = NTERMS - 2; i >= 0; --i) {
+      const cplx<T> y = ytile[i * KQ + j + el * NT];
+      h = mk<T>(h.x * rho.x - h.y * rho.y + y.x, h.x * rho.y + h.y * rho.x + y.y);
+    }
+    re[E0 + el] = h.x * cur.x - h.y * cur.y;
+    im[E0 + el] = h.x * cur.y + h.y * cur.x;
+    if constexpr (PH + 1 < NQ) {       // finish the slot before the next phase overwrites the tiles: left alone the
+      keep_here(re[E0 + el]);         // compiler sinks this arithmetic below the barrier and spills the NTERMS raw
+      keep_here(im[E0 + el]);         // tile values per slot instead of keeping the one result
+    }
+    const int dn = (d + NT) & (K - 1);
+    cur = cmul<T>(cur, dn < d ? stepw : step);
+    d = dn;
+  }
+  if constexpr (PH + 1 < NQ)
+    narrow_phases<T, LOGK, LOGP, NTERMS, NQ, PH + 1>(xhat, rd, mo, N, ytile, j, rho, step, stepw, cur, d, re, im);
+}
+
 template <typename T, int LOGK, int LOGP, int NTERMS>
 __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
                                                const Mother& mo, const cplx<T>* __restrict__ tw_all,
@@ -509,41 +547,30 @@ __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat,
 
   // Input of the K-point FFT for output residue r (n = R m + r):
   //   Z_r[q] = sum_{i < nterms} Y[k_i(q)] e^{2 pi i k_i(q) r / N},  k_i(q) = k_lo + ((q - k_lo) mod K) + i K
-  // NTERMS = 1 for rows whose support fits K bins; 2..4 terms otherwise (K = 1024 only), which
-  // still beats a two-pass transform because the row then needs no intermediate in memory.
+  // NTERMS = 1 for rows whose support fits K bins; several terms otherwise (K >= 1024 only), which
+  // still beats a two-pass transform while the row needs no intermediate in memory.
   // Per term: the Y tile (K complex) is built cooperatively in LDS, then every thread walks its 16
   // inputs with a running twiddle that advances by e^{2 pi i NT r / N} per slot and by an extra
   // e^{-2 pi i K r / N} where k_0(q) wraps around the band start.
+  // The exchange buffer holds P reals = P/2 complex = BT tiles of K bins.  More terms than that go through it in NQ
+  // phases over the FFT input index: phase ph holds all NTERMS terms of the K/NQ inputs q in [ph K/NQ, (ph+1) K/NQ),
+  // i.e. of the thread's slots e in [ph 16/NQ, (ph+1) 16/NQ), which are finished (Horner, twiddle) before the next
+  // phase overwrites the tiles -- nothing but finished FFT inputs stays in registers across the phases.
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
   const unsigned nm = unsigned(N - 1);
-  for (int idx = threadIdx.x; idx < (NTERMS << LOGK); idx += (1 << (LOGP - 4))) {
-    const int q = idx & (K - 1);
-    const int d = (q - rd.k_lo) & (K - 1);
-    ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + d + (idx & ~(K - 1)), N - 1);
-  }
-  __syncthreads();
-  // Z_r[q] = e^{2 pi i k_0(q) r / N} * sum_i Y_i[q] rho^i (Horner), rho = e^{2 pi i K r / N}; the common
-  // factor is a running product over the 16 slots that picks up rho^-1 where k_0(q) wraps
+  constexpr int BT = (1 << LOGP) / (2 * K);
+  static_assert(BT >= 1, "tile too small for one term");
+  constexpr int NQ = NTERMS <= BT ? 1 : NTERMS <= 2 * BT ? 2 : NTERMS <= 4 * BT ? 4 : 8;
+  static_assert(NQ <= 8 && NTERMS * (K / NQ) <= BT * K, "too many terms for the exchange buffer");
+  // Z_r[q] = e^{2 pi i k_0(q) r / N} * sum_i Y_i[q] rho^i (Horner), rho = e^{2 pi i K r / N}; the common factor is a
+  // running product over the 16 slots that picks up rho^-1 where k_0(q) wraps
   const cplx<T> step = twn((unsigned(NT) * r) & nm);
   const cplx<T> rho = twn((r << LOGK) & nm);
   const cplx<T> stepw = cmul<T>(step, mk<T>(rho.x, -rho.y));
   int d = (f.j - rd.k_lo) & (K - 1);
   cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
   T re[16], im[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    cplx<T> h = ytile[((NTERMS - 1) << LOGK) + f.j + e * NT];
-#pragma unroll
-    for (int i = NTERMS - 2; i >= 0; --i) {
-      const cplx<T> y = ytile[(i << LOGK) + f.j + e * NT];
-      h = mk<T>(h.x * rho.x - h.y * rho.y + y.x, h.x * rho.y + h.y * rho.x + y.y);
-    }
-    re[e] = h.x * cur.x - h.y * cur.y;
-    im[e] = h.x * cur.y + h.y * cur.x;
-    const int dn = (d + NT) & (K - 1);
-    cur = cmul<T>(cur, dn < d ? stepw : step);
-    d = dn;
-  }
+  narrow_phases<T, LOGK, LOGP, NTERMS, NQ, 0>(xhat, rd, mo, N, ytile, f.j, rho, step, stepw, cur, d, re, im);
   __syncthreads();  // the tiles alias the exchange buffer
   f.run(re, im, lds, tw);
   cplx<T>* wrow = W + long(rd.out_row) * ldw;
@@ -579,6 +606,26 @@ k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 #undef CWT_NARROW_CASE
 }
 
+// Band-limited rows with 5..16 aliased terms of K = 1024 bins (support up to 16384 bins): a kernel of their own so
+// that the common cases above keep their register allocation.
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
+k_narrow_ct_many(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
+                 long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+#define CWT_MANY_CASE(NT_)                                                                           \
+  case NT_: narrow_ct_body<T, 10, LOGP, NT_>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+  switch (rd.nterms) {
+    CWT_MANY_CASE(5) CWT_MANY_CASE(6) CWT_MANY_CASE(7) CWT_MANY_CASE(8) CWT_MANY_CASE(9) CWT_MANY_CASE(10)
+    CWT_MANY_CASE(11) CWT_MANY_CASE(12) CWT_MANY_CASE(13) CWT_MANY_CASE(14) CWT_MANY_CASE(15) CWT_MANY_CASE(16)
+    default: break;
+  }
+#undef CWT_MANY_CASE
+}
+
 // fp64 only: rows whose support needs K = 2048 (or 2..4 aliased terms of 2048 bins, support <= 8192) run with
 // 16384 points per workgroup (1024 threads, 128 KiB of LDS, one workgroup per CU) so that the stores stay
 // 128-byte segments (TB = 8).  Converts rows of support 4096..8192 from the two-pass transform (48 B per
@@ -596,6 +643,10 @@ k_narrow_ct_big(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
     case 2: narrow_ct_body<T, 11, 14, 2>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
     case 3: narrow_ct_body<T, 11, 14, 3>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
     case 4: narrow_ct_body<T, 11, 14, 4>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 5: narrow_ct_body<T, 11, 14, 5>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 6: narrow_ct_body<T, 11, 14, 6>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 7: narrow_ct_body<T, 11, 14, 7>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 8: narrow_ct_body<T, 11, 14, 8>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
     default: break;
   }
 }

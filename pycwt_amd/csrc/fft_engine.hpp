@@ -50,6 +50,18 @@ __device__ __forceinline__ void store_w(cplx<T>* p, T re, T im) {
   __builtin_nontemporal_store(v, reinterpret_cast<vec2*>(p));
 }
 
+// Pins a value to a register at this point of the program (an empty asm that "modifies" it): the compiler must
+// finish computing it here and may not sink the computation past later barriers.  Used where a result is produced
+// long before its use and sinking would keep many more inputs alive than outputs (narrow_phases).
+template <typename T>
+__device__ __forceinline__ void keep_here(T& v) {
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ cplx<T> cmul(cplx<T> a, cplx<T> b) {
   return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

@@ -234,3 +234,28 @@ def test_row_table_cache_two_slots(emu_library):
     per_row, _ = row_errors(W, refs["A"])
     assert per_row.max() < 1e-12
     plan.close()
+
+
+@pytest.mark.parametrize("prec,opts,expect", [
+    (64, {"narrow_terms": 8, "narrow_big": 0}, "narrow_many"),       # K = 1024, 5..8 terms in two LDS batches (fp64)
+    (64, {"narrow_terms": 16, "narrow_big": 0}, "narrow_many"),      # ... up to 16 terms, four batches
+    (64, {"big_terms": 8, "narrow_terms": 1}, "narrow_k2048"),       # K = 2048, up to 8 terms in two batches
+    (32, {"narrow_terms": 8}, "narrow_many"),                        # fp32: 8 terms fit one batch
+    (32, {"narrow_terms": 16}, "narrow_many"),                       # fp32: two batches
+])
+@pytest.mark.parametrize("kind,param", [(orc.MORLET, 6), (orc.DOG, 2)])
+def test_many_aliased_terms_in_lds_batches(emu_library, prec, opts, expect, kind, param):
+    """Supports of 5000..15000 bins in ONE pass: the aliased terms go through LDS in batches (what the exchange buffer
+    holds), the Horner value of every FFT input stays in registers between batches."""
+    N = 1 << 16
+    x = np.random.default_rng(13).standard_normal(N)
+    m = orc.Mother(kind, param)
+    c = 2.9 if kind == orc.MORLET else 2.5
+    sj = c * N / np.array([5000.0, 7000.0, 9000.0, 12500.0, 15500.0, 3000.0])
+    plan = _hip.Plan(N, prec, max_rows=8, lib=emu_library, options=opts)
+    W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+    split, classes = plan.last_split(), plan.row_classes()
+    plan.close()
+    assert split[expect] >= 1, (split, classes)
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m))
+    assert per_row.max() < TOL[prec], (classes, per_row)
