@@ -160,6 +160,7 @@ struct cwt_plan {
                            // fp64); ignored while "profile" is on so that every timed kernel runs alone
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
+  int pass_b_prefetch = 0; // pass B as a 2- or 4-tile walk per workgroup with the next tile's loads in flight
   int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
   // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
   unsigned long long* stamps = nullptr;
@@ -699,6 +700,19 @@ template <typename T, int LOGK, bool CONJ>
 void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
                       const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
+  if constexpr (!CONJ && LOGK == 10) {
+    const unsigned ntiles = 1u << (p->logN - LOGP);
+    if (p->pass_b_prefetch && !p->stamps && ntiles >= 32) {
+      const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+      if (p->pass_b_prefetch == 4)
+        hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 4>), dim3(ntiles / 4, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
+                           rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw), long(ncols));
+      else
+        hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 2>), dim3(ntiles / 2, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
+                           rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw), long(ncols));
+      return;
+    }
+  }
   // half-size tiles keep the store segments >= 128 B only while TB = 2^(LOGP - 1 - LOGK) >= 128 B / sizeof(complex)
   if constexpr (!CONJ && LOGP - 1 - LOGK >= (sizeof(T) == 8 ? 3 : 4)) {
     if (p->pass_b_small) return launch_pass_b_ct_lp<T, LOGK, LOGP - 1, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
@@ -1108,6 +1122,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_small") p->narrow_small = value != 0;
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "pass_b_small") p->pass_b_small = value != 0;
+  else if (k == "pass_b_prefetch") { if (value != 0 && value != 2 && value != 4) return fail(CWT_EINVAL, "pass_b_prefetch: 0, 2 or 4 tiles"); p->pass_b_prefetch = int(value); }
   else if (k == "stamps") {
     if (value < 0 || value > (int64_t(1) << 24)) return fail(CWT_EINVAL, "stamps: record count in [0, 2^24]");
     HIPCHECK(hipSetDevice(p->device));

@@ -862,6 +862,60 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
   stamp<STAMP>(st, 4, true);
 }
 
+// Pass B with the loads of the next tile in flight under the FFT and the stores of the current one (option
+// "pass_b_prefetch"): every workgroup walks NTILES tiles of its row (tile v = blockIdx.x + i * gridDim.x, the same
+// XCD slice under the XCD-aware map), holding two register sets; one workgroup per CU instead of two.
+template <typename T, int LOGK, int LOGP, int NTILES>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 2 : 4))
+k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
+               const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
+  using F = ct::Fft<T, LOGK, LOGTB, false>;
+  const int logR = logN - LOGK;
+  F f;
+  f.j = threadIdx.x & (NT - 1);
+  f.t = threadIdx.x >> LOGNT;
+  const unsigned ntiles = gridDim.x * NTILES;
+  auto tile_r0 = [&](int i) {
+    const unsigned v = blockIdx.x + unsigned(i) * gridDim.x;
+    const unsigned x = (sizeof(T) == 8 && !(ntiles & 7u)) ? (v & 7u) * (ntiles >> 3) + (v >> 3) : v;
+    return x << LOGTB;
+  };
+  const cplx<T>* zrow = Z + (long(blockIdx.y) << logN);
+  const unsigned zoff = (unsigned(f.t) << LOGK) + f.j;
+  const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
+  cplx<T>* wrow = W + orow * ldw;
+  T ar[16], ai[16], br[16], bi[16];
+  {
+    const cplx<T>* z = zrow + (long(tile_r0(0)) << LOGK);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; ar[e] = v.x; ai[e] = v.y; }
+  }
+#pragma unroll
+  for (int i = 0; i < NTILES; i += 2) {
+    if (i + 1 < NTILES) {
+      const cplx<T>* z = zrow + (long(tile_r0(i + 1)) << LOGK);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; br[e] = v.x; bi[e] = v.y; }
+    }
+    f.run(ar, ai, lds, tw);
+    transpose_store<T, LOGK, LOGP, false>(ar, ai, lds, f.t, f.j, wrow, logR, tile_r0(i), ncols);
+    __syncthreads();                                     // LDS is reused by the next tile's FFT
+    if (i + 1 < NTILES) {
+      if (i + 2 < NTILES) {
+        const cplx<T>* z = zrow + (long(tile_r0(i + 2)) << LOGK);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; ar[e] = v.x; ai[e] = v.y; }
+      }
+      f.run(br, bi, lds, tw);
+      transpose_store<T, LOGK, LOGP, false>(br, bi, lds, f.t, f.j, wrow, logR, tile_r0(i + 1), ncols);
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Element-wise helpers of the coherence path (pycwt/wavelet.py:499-514, mothers.py:97-102).
 // All matrices are rows x ld, row-major, n < ncols valid.

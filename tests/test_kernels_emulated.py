@@ -259,3 +259,20 @@ def test_many_aliased_terms_in_lds_batches(emu_library, prec, opts, expect, kind
     assert split[expect] >= 1, (split, classes)
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m))
     assert per_row.max() < TOL[prec], (classes, per_row)
+
+
+@pytest.mark.parametrize("tiles", [2, 4])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_pass_b_with_prefetched_tiles(emu_library, tiles, prec):
+    """Option pass_b_prefetch: every pass-B workgroup walks 2 or 4 tiles with the next tile's loads issued before the
+    current tile's FFT; same rows as the one-tile-per-workgroup kernel."""
+    N = 1 << (18 if prec == 64 else 19)
+    x = np.random.default_rng(17).standard_normal(N - 5)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = 2.9 * N / np.array([250000.0, 40000.0, 17000.0])
+    plan = _hip.Plan(N, prec, max_rows=4, lib=emu_library, options={"pass_b_prefetch": tiles})
+    W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
+    assert plan.last_split()["two_pass"] == 3
+    plan.close()
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m)[:, :x.size])
+    assert per_row.max() < TOL[prec], per_row
