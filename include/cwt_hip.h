@@ -115,6 +115,15 @@ int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double 
                        const double* scales_host, int nrows, void* W_dev, int64_t ldw,
                        int64_t ncols);
 
+/* The same two steps at a transform length n0 that is NOT a power of two -- what the reference computes when pyfftw is
+ * installed: helpers.py:15-19 then passes n = len(signal), i.e. no zero padding and circular edges -- by Bluestein's
+ * chirp-z identity on this plan's power-of-two engine.  The plan must have nfft >= 2*n0 - 1.  xhat_dev: n0 complex
+ * (FFT order, xhat[k] = sum_n x[n] exp(-2*pi*i*k*n/n0)); W_dev: nrows x ldw complex, n0 columns written per row;
+ * w_k = 2*pi*fftfreq(n0, dt)[k].  Any nrows (processed in slabs of at most max_rows rows).                          */
+int cwt_forward_fft_n(cwt_plan* plan, const void* x_dev, int64_t n0, void* xhat_dev);
+int cwt_transform_rows_n(cwt_plan* plan, const void* xhat_dev, int64_t n0, int mother, double param, double dt,
+                         const double* scales_host, int nrows, void* W_dev, int64_t ldw);
+
 /* Batch of equally long signals sharing one scale grid (BASELINE config 4): xhat_dev holds nbatch
  * spectra (signal b at xhat_dev + b*xhat_ld, e.g. written by cwt_fft_rows), W_dev is
  * nbatch x nrows x ldw: W[b, j, :] = row j of signal b.  One set of launches covers the whole batch

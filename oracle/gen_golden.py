@@ -15,6 +15,7 @@ Cases:
   big_paul/dog   same N, config 3 grids (fp64 values), 5 rows each
   callers        significance / xwt / Morlet.smooth / wct (deterministic part)
   mc_significance  wct_significance with np.random.seed (two small cases) + rednoise seed for seed
+  unpadded       the pyfftw branch (transform length = len(signal), helpers.py:15-19) at n0 = 504, 1000, 331
 The signal itself is stored too (NINO3 data is 504 floats).
 """
 import os
@@ -159,6 +160,25 @@ def callers():
     save("callers", **out)
 
 
+def unpadded():
+    """The reference's pyfftw branch (helpers.py:15-19): `fft_kwargs` returns n = len(signal), so nothing is padded.
+    pyfftw is not installed here; the branch is reproduced by giving the unmodified `wavelet.cwt` exactly that
+    `fft_kwargs` (the FFT itself stays scipy.fftpack, the same arithmetic as pyfftw's scipy_fftpack interface)."""
+    import pycwt.wavelet as rw
+    keep = rw.fft_kwargs
+    rw.fft_kwargs = lambda signal, **kw: {"n": len(signal)}
+    try:
+        out = {}
+        for tag, n0, name in (("a", 504, "morlet"), ("b", 1000, "paul"), ("c", 331, "dog")):
+            x = np.random.default_rng(n0).standard_normal(n0)
+            W, sj, freqs, coi, fft, fftfreqs = ref.cwt(x, 0.5, 1 / 4, -1, -1, mother_of(name))
+            out.update({f"{tag}_x": x, f"{tag}_W": W, f"{tag}_sj": sj, f"{tag}_freqs": freqs, f"{tag}_coi": coi,
+                        f"{tag}_fft": fft, f"{tag}_fftfreqs": fftfreqs, f"{tag}_name": name})
+        save("unpadded", **out)
+    finally:
+        rw.fft_kwargs = keep
+
+
 def mc_significance():
     """Seeded Monte-Carlo coherence significance (wavelet.py:531-647): the reference draws from the global NumPy RNG
     (helpers.py:170), one series BEFORE the loop (wavelet.py:594) and two per draw, so a seed pins the whole result."""
@@ -182,9 +202,13 @@ if __name__ == "__main__":
     if "--mc-only" in sys.argv:
         mc_significance()
         sys.exit(0)
+    if "--unpadded-only" in sys.argv:
+        unpadded()
+        sys.exit(0)
     callers()
     sys.exit(0) if "--callers-only" in sys.argv else None
     mc_significance()
+    unpadded()
     nino3()
     small()
     mid()

@@ -36,6 +36,9 @@ SYMBOLS = [
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_forward_fft_n", C.c_int, [_P, _P, C.c_int64, _P]),
+    ("cwt_transform_rows_n", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                       C.c_int, _P, C.c_int64]),
     ("cwt_transform_rows_batch", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double,
                                            C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
     ("cwt_transform_rows_table", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P,
@@ -181,6 +184,18 @@ class Plan:
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform_rows(self.h, _P(xhat_dev), mother, float(param), float(dt),
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
+
+    @_locked
+    def forward_fft_n(self, x_dev: int, n0: int, xhat_dev: int):
+        """Forward transform at length n0 (not a power of two; this plan's nfft >= 2*n0 - 1)."""
+        self.lib.check(self.lib.cwt_forward_fft_n(self.h, _P(x_dev), n0, _P(xhat_dev)))
+
+    @_locked
+    def transform_rows_n(self, xhat_dev: int, n0: int, mother: int, param: float, dt: float, scales, W_dev: int,
+                         ldw: int):
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_transform_rows_n(self.h, _P(xhat_dev), n0, mother, float(param), float(dt),
+                                                     _dptr(s), s.size, _P(W_dev), ldw))
 
     @_locked
     def transform_rows_batch(self, xhat_dev: int, nbatch: int, xhat_ld: int, mother: int, param: float,

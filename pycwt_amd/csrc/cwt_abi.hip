@@ -200,6 +200,12 @@ struct cwt_plan {
   int split[5] = {0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
                                     // band-limited K = 2048, band-limited K = 1024 with 5..16 terms
   HostCopier* copier = nullptr;       // created by the first large device -> host copy
+  // Bluestein state for transform lengths n0 that are not powers of two (this plan's N is then M >= 2 n0 - 1)
+  int64_t bs_n0 = 0;
+  void* bs_khat[2] = {nullptr, nullptr};   // FFT_M of the chirp kernels: [0] e^{+pi i m^2/n0} (forward), [1] conjugate
+  void* bs_a = nullptr; size_t bs_a_bytes = 0;          // chirp-premultiplied rows, slab x n0
+  void* bs_spec = nullptr; size_t bs_spec_bytes = 0;    // their spectra, slab x M
+  void* bs_par = nullptr; size_t bs_par_bytes = 0;      // per-row a, amp_re, amp_im (doubles)
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
@@ -351,7 +357,7 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
 // a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
 int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
                     const double* amp_im, int64_t spec_ld, int nrows, const int* tab_klo = nullptr,
-                    const int* tab_nband = nullptr, int rows_per_signal = 0) {
+                    const int* tab_nband = nullptr, int rows_per_signal = 0, int64_t tab_ld = -1) {
   const int64_t N = p->N;
   double f_lo = 0, f_hi = 0;
   if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
@@ -379,7 +385,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.amp_im = amp_im[j] / double(N);
     // batched signals: row j belongs to signal j / rows_per_signal, whose spectrum starts at spec_ld * that
     rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
-    rd.tab_off = long(N) * j;
+    rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
     klo = std::max(klo, -double(N / 2));
@@ -1073,7 +1079,8 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps};
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps,
+                  p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
     if (t.rows_dev) (void)hipFree(t.rows_dev);
@@ -1528,6 +1535,132 @@ int cwt_coherence_histogram(cwt_plan* p, const void* r2_dev, int64_t ld, int nro
                          static_cast<const float*>(r2_dev), long(ld), reinterpret_cast<const long*>(lo_dev),
                          reinterpret_cast<const long*>(hi_dev), nbins, reinterpret_cast<unsigned long long*>(hist_dev));
   });
+}
+
+extern "C++" {
+namespace {
+// Chirp-kernel spectra for length n0 on this plan (N = M >= 2 n0 - 1), cached per n0.
+template <typename T>
+int bluestein_prepare(cwt_plan* p, int64_t n0) {
+  if (n0 < 1 || 2 * n0 - 1 > p->N) return fail(CWT_EINVAL, "this plan's nfft must be >= 2*n0 - 1 for a length-n0 transform");
+  if (p->bs_n0 == n0) return CWT_OK;
+  p->bs_n0 = 0;
+  const size_t bytes = size_t(p->N) * sizeof(cplx<T>);
+  int rc = grow(&p->bs_a, &p->bs_a_bytes, bytes, p->stream);      // staging for the kernel in the time domain
+  for (int i = 0; i < 2 && !rc; ++i) {
+    if (!p->bs_khat[i] && hipMalloc(&p->bs_khat[i], bytes) != hipSuccess) return fail(CWT_ENOMEM, "chirp table allocation failed");
+    const unsigned blocks = unsigned((p->N + 255) / 256);
+    hipLaunchKernelGGL((k_chirp_kernel<T>), dim3(blocks), dim3(256), 0, p->stream, long(n0), long(p->N), i == 0 ? +1 : -1,
+                       static_cast<cplx<T>*>(p->bs_a));
+    HIPCHECK(hipGetLastError());
+    rc = fft_rows_impl<T, IN_CPLX>(p, p->bs_a, p->N, 1, p->N, p->bs_khat[i]);
+  }
+  if (rc) return rc;
+  p->bs_n0 = n0;
+  return CWT_OK;
+}
+
+// out[j, 0..n0) = IFFT_M( spec[j, :] * khat[which] ), rows x ldo; the table inverse of the engine with one shared table
+template <typename T>
+int bluestein_convolve(cwt_plan* p, const void* spec, int nrows, int which, void* out, int64_t ldo, int64_t n0) {
+  select_table(p, {});
+  std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
+  std::vector<int> klo(nrows, int(-(p->N / 2))), nb(nrows, int(p->N));
+  int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), p->N, nrows, klo.data(), nb.data(),
+                           0, 0);
+  if (!rc) rc = upload_row_table(p, {});
+  if (rc) return rc;
+  set_split(p);
+  Mother mo;
+  mo.kind = MOTHER_TABLE; mo.m = 0; mo.p = 0; mo.table = p->bs_khat[which];
+  return rows_impl<T>(p, spec, mo, nrows, out, ldo, n0);
+}
+
+template <typename T>
+int forward_fft_n_impl(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
+  int rc = bluestein_prepare<T>(p, n0);
+  if (!rc) rc = grow(&p->bs_a, &p->bs_a_bytes, size_t(p->N) * sizeof(cplx<T>), p->stream);
+  if (!rc) rc = grow(&p->bs_spec, &p->bs_spec_bytes, size_t(p->N) * sizeof(cplx<T>), p->stream);
+  if (rc) return rc;
+  const dim3 grid(unsigned((n0 + 255) / 256), 1);
+  // a[n] = x[n] conj(c[n]);  xhat[k] = conj(c[k]) * (a conv c)[k]
+  hipLaunchKernelGGL((k_chirp_mul<T, IN_REAL>), grid, dim3(256), 0, p->stream, x_dev, long(n0), long(n0), -1, 1.0,
+                     static_cast<cplx<T>*>(p->bs_a), long(n0));
+  HIPCHECK(hipGetLastError());
+  rc = fft_rows_impl<T, IN_CPLX>(p, p->bs_a, n0, 1, n0, p->bs_spec);
+  if (!rc) rc = bluestein_convolve<T>(p, p->bs_spec, 1, 0, xhat_dev, n0, n0);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_chirp_mul<T, IN_CPLX>), grid, dim3(256), 0, p->stream, xhat_dev, long(n0), long(n0), -1, 1.0,
+                     static_cast<cplx<T>*>(xhat_dev), long(n0));
+  HIPCHECK(hipGetLastError());
+  return CWT_OK;
+}
+
+template <typename T>
+int transform_rows_n_impl(cwt_plan* p, const void* xhat_dev, int64_t n0, int mother, double param, double dt,
+                          const double* scales, int nrows, void* W_dev, int64_t ldw) {
+  double cre, cim;
+  int rc = mother_constant(mother, param, &cre, &cim);
+  if (!rc) rc = bluestein_prepare<T>(p, n0);
+  if (rc) return rc;
+  const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(n0) * dt));    // ftfreqs[1] at length n0
+  std::vector<double> par(size_t(3) * nrows);
+  for (int j = 0; j < nrows; ++j) {
+    if (!(scales[j] > 0) || !std::isfinite(scales[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
+    const double norm = std::sqrt(scales[j] * w1 * double(n0));                   // wavelet.py:102
+    par[j] = scales[j] * w1;
+    par[nrows + j] = norm * cre;
+    par[2 * size_t(nrows) + j] = norm * cim;
+  }
+  rc = grow(&p->bs_par, &p->bs_par_bytes, par.size() * sizeof(double), p->stream);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(p->bs_par, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIPCHECK(hipStreamSynchronize(p->stream));            // `par` is pageable and dies with this frame
+  const double* dpar = static_cast<const double*>(p->bs_par);
+  const int slab = int(std::max<size_t>(1, std::min<size_t>(size_t(std::min(nrows, p->max_rows)),
+                                                           (size_t(1) << 31) / (size_t(p->N) * sizeof(cplx<T>)))));
+  rc = grow(&p->bs_a, &p->bs_a_bytes, std::max(size_t(p->N), size_t(slab) * size_t(n0)) * sizeof(cplx<T>), p->stream);
+  if (!rc) rc = grow(&p->bs_spec, &p->bs_spec_bytes, size_t(slab) * size_t(p->N) * sizeof(cplx<T>), p->stream);
+  if (rc) return rc;
+  Mother mo;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
+  for (int first = 0; first < nrows; first += slab) {
+    const int cnt = std::min(slab, nrows - first);
+    const dim3 grid(unsigned((n0 + 255) / 256), unsigned(cnt));
+    hipLaunchKernelGGL((k_bluestein_band<T>), grid, dim3(256), 0, p->stream, static_cast<const cplx<T>*>(xhat_dev),
+                       dpar + first, dpar + nrows + first, dpar + 2 * size_t(nrows) + first, mo, long(n0),
+                       static_cast<cplx<T>*>(p->bs_a), long(n0));
+    HIPCHECK(hipGetLastError());
+    rc = fft_rows_impl<T, IN_CPLX>(p, p->bs_a, n0, cnt, n0, p->bs_spec);
+    cplx<T>* Wslab = static_cast<cplx<T>*>(W_dev) + size_t(first) * size_t(ldw);
+    if (!rc) rc = bluestein_convolve<T>(p, p->bs_spec, cnt, 1, Wslab, ldw, n0);
+    if (rc) return rc;
+    // W[j, n] = c[n] / n0 * conv[n]
+    hipLaunchKernelGGL((k_chirp_mul<T, IN_CPLX>), grid, dim3(256), 0, p->stream, static_cast<const void*>(Wslab), long(ldw),
+                       long(n0), +1, 1.0 / double(n0), Wslab, long(ldw));
+    HIPCHECK(hipGetLastError());
+  }
+  return CWT_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int cwt_forward_fft_n(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
+  if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? forward_fft_n_impl<double>(p, x_dev, n0, xhat_dev) : forward_fft_n_impl<float>(p, x_dev, n0, xhat_dev);
+}
+
+int cwt_transform_rows_n(cwt_plan* p, const void* xhat_dev, int64_t n0, int mother, double param, double dt,
+                         const double* scales, int nrows, void* W_dev, int64_t ldw) {
+  if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 1) return fail(CWT_EINVAL, "nrows must be >= 1");
+  if (ldw < n0) return fail(CWT_EINVAL, "ldw must be >= n0");
+  if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
+  if (mother < MOTHER_MORLET || mother > MOTHER_DOG) return fail(CWT_EINVAL, "unknown mother id");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? transform_rows_n_impl<double>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw)
+                       : transform_rows_n_impl<float>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw);
 }
 
 int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, double param, double dt,

@@ -1001,6 +1001,61 @@ __global__ void k_wct_coherence(const cplx<T>* __restrict__ S, const cplx<T>* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Transform lengths that are not powers of two (the reference's pyfftw branch transforms at len(signal) without
+// padding, helpers.py:15-19): Bluestein's identity 2kn = k^2 + n^2 - (k - n)^2 turns a length-n0 DFT into chirp
+// multiplications and one circular convolution of power-of-two length M >= 2 n0 - 1, which runs on the FFT engine.
+// chirp(m) = e^{sgn * pi i m^2 / n0}; m^2 is reduced mod 2 n0 in integers, so the angle is exact to the last bit.
+__device__ __forceinline__ void chirp(long m, long n0, int sgn, double* c, double* s) {
+  const unsigned long long r = (unsigned long long)(m * m) % (unsigned long long)(2 * n0);
+  sincospi(double(sgn) * double(r) / double(n0), s, c);
+}
+
+// out[r, n] = in[r, n] * chirp(n) * scale, n < n0.  MODE IN_REAL: real input; IN_CPLX: complex input (out may be in).
+template <typename T, int MODE>
+__global__ void k_chirp_mul(const void* in, long in_ld, long n0, int sgn, double scale, cplx<T>* out, long out_ld) {
+  const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= n0) return;
+  double c, s;
+  chirp(n, n0, sgn, &c, &s);
+  c *= scale; s *= scale;
+  const long r = blockIdx.y;
+  double xr, xi = 0;
+  if constexpr (MODE == IN_REAL) xr = double((static_cast<const T*>(in) + r * in_ld)[n]);
+  else { const cplx<T> v = (static_cast<const cplx<T>*>(in) + r * in_ld)[n]; xr = v.x; xi = v.y; }
+  out[r * out_ld + n] = mk<T>(T(xr * c - xi * s), T(xr * s + xi * c));
+}
+
+// The convolution kernel of length M: b[m] = chirp(m) for |m| < n0 (indices mod M), 0 elsewhere.
+template <typename T>
+__global__ void k_chirp_kernel(long n0, long M, int sgn, cplx<T>* b) {
+  const long m = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const long dist = m < n0 ? m : (M - m < n0 ? M - m : -1);
+  double c = 0, s = 0;
+  if (dist >= 0) chirp(dist, n0, sgn, &c, &s);
+  b[m] = mk<T>(T(c), T(s));
+}
+
+// A[j, k] = xhat[k] * amp_j * profile(a_j * signed_bin(k)) * chirp(k), k < n0: the filtered spectrum of row j
+// (wavelet.py:102-105 at transform length n0) premultiplied for the inverse Bluestein convolution.
+template <typename T>
+__global__ void k_bluestein_band(const cplx<T>* __restrict__ xhat, const double* __restrict__ a,
+                                 const double* __restrict__ amp_re, const double* __restrict__ amp_im, Mother mo,
+                                 long n0, cplx<T>* __restrict__ A, long ld) {
+  const long k = long(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  const int j = blockIdx.y;
+  const long sk = k < (n0 + 1) / 2 ? k : k - n0;          // numpy.fft.fftfreq order for even and odd n0
+  const double g = profile<double>(mo, a[j] * double(sk));
+  const double gr = g * amp_re[j], gi = g * amp_im[j];
+  const cplx<T> x = xhat[k];
+  const double yr = double(x.x) * gr - double(x.y) * gi, yi = double(x.x) * gi + double(x.y) * gr;
+  double c, s;
+  chirp(k, n0, +1, &c, &s);
+  A[long(j) * ld + k] = mk<T>(T(yr * c - yi * s), T(yr * s + yi * c));
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_icwt: out[n] = coeff * sum_j g(W[j, n]) * w[j]; POWER = false: g = Re (TC98 eq. 11 with w = 1/sqrt(s_j),
 // wavelet.py:169-170); POWER = true: g = |.|^2 (scale-averaged power with w = 1/s_j on the selected scales,
 // TC98 eq. 24 as used in sample/simple_sample.py:87-91)

@@ -150,22 +150,51 @@ def _cwt_with_host_filter_bank(x, dt, sj, mother, N, precision, device):
         sc.free()
 
 
+def _cwt_unpadded(x, dt, sj, kind, param, precision, device):
+    """W (rows x n0) and the spectrum (n0) at transform length n0 = len(x), not a power of two: Bluestein's chirp-z
+    identity on the power-of-two engine (cwt_forward_fft_n / cwt_transform_rows_n)."""
+    n0 = x.size
+    M = _next_pow2(2 * n0 - 1)
+    plan = _plan(M, precision, device, min(sj.size, 1024))
+    es = np.dtype(plan.real).itemsize
+    sc = _Scratch(device)
+    try:
+        xd, xh, Wd = sc.new(n0 * es), sc.new(n0 * 2 * es), sc.new(sj.size * n0 * 2 * es)
+        with plan.lock:
+            xd.upload(plan, x)
+            plan.forward_fft_n(xd.ptr, n0, xh.ptr)
+            plan.transform_rows_n(xh.ptr, n0, kind, param, dt, sj, Wd.ptr, n0)
+            return Wd.download(plan, (sj.size, n0), plan.cplx), xh.download(plan, (n0,), plan.cplx)
+    finally:
+        sc.free()
+
+
 def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
-        device=0):
+        device=0, pad=True):
     """Continuous wavelet transform; drop-in for ``pycwt.cwt`` (wavelet.py:13-124).
 
     Returns ``(W[:, :n0], sj, freqs, coi, fft, fftfreqs)`` exactly as the reference does.  ``W`` is
     complex128; ``precision=32`` (or ``PYCWT_AMD_PRECISION=32``) computes in complex64 on the GPU
     (1e-3 relative parity) and widens on return.  Keyword-only extras do not disturb positional use.
+
+    ``pad=True`` is the reference with its scipy.fftpack backend: the transform length is the next power of
+    two (helpers.py:27-30).  ``pad=False`` is the reference with pyfftw installed: the transform length is
+    ``len(signal)`` itself (helpers.py:15-19), no zero padding, circular edges, any length.
     """
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     n0 = len(signal)
     sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
 
-    N = _next_pow2(n0)
+    N = _next_pow2(n0) if pad else n0
     real = np.float64 if precision == 64 else np.float32
-    if hasattr(mother, "device_id"):
+    if N != _next_pow2(N):                                  # pad=False with a length that is not a power of two
+        bad = _nan_rows(mother, sj, N, dt)
+        if bad.any() and not bad.all():
+            sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
+        kind, param = _device_id(mother)
+        W, xhat = _cwt_unpadded(np.ascontiguousarray(signal, dtype=real), dt, sj, kind, param, precision, device)
+    elif hasattr(mother, "device_id"):
         bad = _nan_rows(mother, sj, N, dt)
         if bad.any() and not bad.all():                     # wavelet.py:111-115
             keep = ~bad

@@ -62,6 +62,11 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 #define __builtin_amdgcn_s_getreg(imm) (0u)
 static inline unsigned long long wall_clock64() { return 0ull; }
+static inline void sincospi(double x, double* s, double* c) {
+  const double r = std::fmod(x, 2.0);                       // exact; keeps the argument of sin/cos small
+  *s = std::sin(3.14159265358979323846 * r);
+  *c = std::cos(3.14159265358979323846 * r);
+}
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __expf(x) expf(x)
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::cur->smem);

@@ -539,3 +539,21 @@ def test_config4_full_batch_sampled_pairs(hip_library):
     plan.close()
     print(f"config 4 full batch: {len(pairs)} (signal, scale) pairs, worst row error {worst:.3e}")
     assert worst < TOL[64]
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-11), (32, 2e-4)])
+def test_unpadded_transform_lengths_on_gpu(hip_library, precision, tol):
+    """pad=False (the reference's pyfftw branch, helpers.py:15-19): reference-generated fixture at n0 = 504 / 1000 / 331
+    and the oracle at n0 = 65521 (prime) and 1 000 003."""
+    g = load_golden("unpadded")
+    for tag in "abc":
+        out = pycwt_amd.cwt(g[f"{tag}_x"], 0.5, 1 / 4, -1, -1, str(g[f"{tag}_name"]), pad=False, precision=precision)
+        per_row, l2 = row_errors(out[0], g[f"{tag}_W"])
+        assert out[0].shape == g[f"{tag}_W"].shape and per_row.max() < tol and l2 < tol, (tag, per_row.max())
+        np.testing.assert_allclose(out[4], g[f"{tag}_fft"], rtol=0, atol=tol * np.abs(g[f"{tag}_fft"]).max())
+    for n0, dj in ((65521, 1.0), (1000003, 4.0)):
+        x = np.random.default_rng(n0).standard_normal(n0)
+        out = pycwt_amd.cwt(x, 1.0, dj, -1, -1, "morlet", pad=False, precision=precision)
+        ref = orc.cwt(x.astype(np.float32) if precision == 32 else x, 1.0, dj, -1, -1, "morlet", pad=False)
+        per_row, _ = row_errors(out[0], ref[0])
+        assert out[0].shape == ref[0].shape and per_row.max() < tol, (n0, per_row.max())

@@ -135,3 +135,15 @@ def test_live_reference(name):
             np.testing.assert_allclose(orc.icwt(out[0], out[1], 0.3, 1 / 6, name),
                                        ref.icwt(out_ref[0], out_ref[1], 0.3, 1 / 6, name),
                                        rtol=1e-12, atol=1e-13)
+
+
+def test_unpadded_branch_of_the_reference():
+    """oracle.cwt(pad=False) against the reference's pyfftw branch (fft_kwargs -> n = len(signal), helpers.py:15-19;
+    fixture made by oracle/gen_golden.py: unpadded)."""
+    g = load_golden("unpadded")
+    for tag in "abc":
+        out = orc.cwt(g[f"{tag}_x"], 0.5, 1 / 4, -1, -1, str(g[f"{tag}_name"]), pad=False)
+        per_row, l2 = row_errors(out[0], g[f"{tag}_W"])
+        assert out[0].shape == g[f"{tag}_W"].shape and per_row.max() < 1e-12 and l2 < 1e-12
+        for got, key in zip(out[1:], ("sj", "freqs", "coi", "fft", "fftfreqs")):
+            np.testing.assert_allclose(got, g[f"{tag}_{key}"], rtol=1e-12, atol=1e-13)

@@ -228,3 +228,32 @@ def test_rejected_option_leaves_the_plan_usable(emulated):
         np.testing.assert_array_equal(W, W0)
     assert np.abs(W0 - ref).max() < 1e-12 * np.abs(ref).max()
     plan.close()
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-11), (32, 2e-4)])
+def test_unpadded_transform_lengths_bluestein(emulated, precision, tol):
+    """pad=False: the reference with pyfftw transforms at len(signal) (helpers.py:15-19).  Lengths that are not powers
+    of two run through Bluestein's identity on the power-of-two engine; fixture from the reference's own branch."""
+    g = load_golden("unpadded")
+    for tag in "abc":
+        x, name = g[f"{tag}_x"], str(g[f"{tag}_name"])
+        out = pycwt_amd.cwt(x, 0.5, 1 / 4, -1, -1, name, pad=False, precision=precision)
+        assert out[0].shape == g[f"{tag}_W"].shape and out[0].dtype == np.complex128
+        per_row, l2 = row_errors(out[0], g[f"{tag}_W"])
+        assert per_row.max() < tol and l2 < tol, (tag, per_row.max())
+        np.testing.assert_allclose(out[1], g[f"{tag}_sj"], rtol=1e-15)
+        np.testing.assert_allclose(out[3], g[f"{tag}_coi"], rtol=1e-15)
+        np.testing.assert_allclose(out[4], g[f"{tag}_fft"], rtol=0, atol=tol * np.abs(g[f"{tag}_fft"]).max())
+        np.testing.assert_allclose(out[5], g[f"{tag}_fftfreqs"], rtol=1e-15)
+
+
+@pytest.mark.parametrize("n0", [3, 17, 1000, 4097, 65521])
+def test_unpadded_lengths_against_the_oracle(emulated, n0):
+    x = np.random.default_rng(n0).standard_normal(n0)
+    for name in ("morlet", "dog"):
+        out = pycwt_amd.cwt(x, 1.0, 1.0, -1, -1, name, pad=False)
+        ref = orc.cwt(x, 1.0, 1.0, -1, -1, name, pad=False)
+        assert out[0].shape == ref[0].shape
+        per_row, _ = row_errors(out[0], ref[0])
+        assert per_row.max() < 1e-11, (n0, name, per_row.max())
+        np.testing.assert_allclose(out[4], ref[4], rtol=0, atol=1e-11 * max(np.abs(ref[4]).max(), 1e-300) if ref[4].size else 0)
