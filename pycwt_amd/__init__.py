@@ -5,11 +5,11 @@ from pycwt/wavelet.py); the arithmetic runs in hand-written HIP kernels (pycwt_a
 through the C ABI of include/cwt_hip.h.  Importing this package does not need a GPU; calling
 ``cwt`` / ``icwt`` does, and fails loudly without one.
 """
-from . import helpers
-from .helpers import ar1, ar1_spectrum, find, get_cache_dir, rednoise
+from . import helpers, mothers
+from .helpers import ar1, ar1_spectrum, fft, fft_kwargs, find, get_cache_dir, rednoise
 from .mothers import DOG, MexicanHat, Morlet, Paul
 from .wavelet import DeviceTransform, cwt, cwt_batch, cwt_device, icwt, significance, wct, wct_significance, xwt
 
 __version__ = "0.1.0"
 __all__ = ["cwt", "cwt_batch", "cwt_device", "DeviceTransform", "icwt", "significance", "xwt", "wct", "wct_significance", "Morlet", "Paul", "DOG",
-           "MexicanHat", "ar1", "ar1_spectrum", "rednoise", "find", "get_cache_dir", "helpers"]
+           "MexicanHat", "ar1", "ar1_spectrum", "rednoise", "find", "get_cache_dir", "helpers", "mothers", "fft", "fft_kwargs"]

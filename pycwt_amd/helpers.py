@@ -13,6 +13,21 @@ import numpy as np
 from scipy.signal import lfilter
 
 
+# The reference's FFT seam (helpers.py:6-30): a module object `fft` with fft/ifft/fftfreq and `fft_kwargs(signal)`
+# giving the padded length.  pycwt_amd.cwt does not go through it (the transforms run on the GPU); the names stay so
+# that code which reaches for `pycwt.fft` / `pycwt.helpers.fft_kwargs` (leaked into the package namespace by
+# `from .wavelet import *`, pycwt/__init__.py:85) keeps resolving, with the scipy.fftpack branch's semantics.
+import scipy.fftpack as fft  # noqa: E402
+
+_FFT_NEXT_POW2 = True
+
+
+def fft_kwargs(signal, **kwargs):
+    """Next power of two >= len(signal) as the transform length (helpers.py:27-30)."""
+    if _FFT_NEXT_POW2:
+        return {"n": int(2 ** np.ceil(np.log2(len(signal))))}
+
+
 def find(condition):
     """Indices of the true entries of the flattened condition (helpers.py:37-40)."""
     return np.flatnonzero(np.ravel(condition))
