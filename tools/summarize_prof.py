@@ -26,20 +26,29 @@ def short(name):
 def klass(name):
     if name.startswith("k_narrow_ct_big"):
         return "narrow_big"
+    if name.startswith("k_narrow_ct_many"):
+        return "narrow_many"
     for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
         if name.startswith(k):
-            fwd = name.rstrip(">").endswith(", 1") or name.rstrip(">").endswith("true")
-            return ("fwd_" if fwd and k in ("k_pass_a", "k_pass_b") else "") + k[2:]
+            args = name[name.find("<") + 1:name.rfind(">")].split(", ") if "<" in name else []
+            fwd = False
+            if name.startswith("k_pass_b_ct") and len(args) >= 4:
+                fwd = args[3] == "true"                       # CONJ: the forward FFT of the signal
+            elif name.startswith("k_pass_a_ct<") and args:
+                fwd = args[-1] in ("1", "2")                  # MODE IN_REAL / IN_CPLX
+            return ("fwd_" if fwd else "") + k[2:]
     return None
 
 
 stats = {}
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    print("== kernel stats", os.path.relpath(f, root))
-    for row in csv.DictReader(open(f)):
-        print(f"{short(row['Name']):60s} calls {row['Calls']:>6s} total_ns {row['TotalDurationNs']:>12s} "
-              f"avg_ns {float(row['AverageNs']):12.1f} pct {row['Percentage']}")
-        stats[short(row["Name"])] = (int(row["Calls"]), float(row["TotalDurationNs"]))
+for sub, label in (("trace", "default command"), ("trace_ser", "--opt overlap_narrow=0: every kernel alone")):
+    for f in glob.glob(os.path.join(root, sub, "**", "*kernel_stats.csv"), recursive=True):
+        print(f"== kernel stats {os.path.relpath(f, root)} ({label})")
+        for row in csv.DictReader(open(f)):
+            print(f"{short(row['Name']):60s} calls {row['Calls']:>6s} total_ns {row['TotalDurationNs']:>12s} "
+                  f"avg_ns {float(row['AverageNs']):12.1f} pct {row['Percentage']}")
+            if sub == "trace_ser" or short(row["Name"]) not in stats:
+                stats[short(row["Name"])] = (int(row["Calls"]), float(row["TotalDurationNs"]))
 
 pmc = defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
