@@ -86,6 +86,12 @@ class Runtime:
             torch.cuda.set_device(self.local)
             self.dev = torch.device("cuda", self.local)
             self.device_index = self.local
+        self.shard = (self.rank, self.world)              # (R, G): this process computes rows j = R mod G
+        if args.shard:
+            r, g = (int(v) for v in args.shard.split("/"))
+            if self.world != 1 or not 0 <= r < g:
+                raise SystemExit("--shard R/G is a single-process diagnostic with 0 <= R < G")
+            self.shard = (r, g)
         self.backend = args.backend or ("gloo" if self.emulate else "nccl")
         self.use_dist = self.world > 1 or args.force_dist
         if self.use_dist:
@@ -135,7 +141,7 @@ class Workload:
         self.kind, self.param, self.prec, self.label = CONFIGS[config]
         self.N, self.dt, self.rows_total = 1 << logn, 1.0, rows_total
         self.sj_all = scale_grid(self.N, self.dt, flambda_of(self.kind, self.param), rows_total)
-        self.mine = np.arange(rt.rank, rows_total, rt.world)
+        self.mine = np.arange(rt.shard[0], rows_total, rt.shard[1])
         self.sj = np.ascontiguousarray(self.sj_all[self.mine])
         real_t = torch.float64 if self.prec == 64 else torch.float32
         cplx_t = torch.complex128 if self.prec == 64 else torch.complex64
@@ -218,7 +224,7 @@ class Workload:
         alg_bytes_total = float(N) * len(self.sj) * self.csize + N * (self.csize // 2)
         traffic = None                  # HBM bytes per launch of the dominant kernel, from committed PMC passes
         tpath = os.path.join(ROOT, "profiles", f"traffic_{self.config}.json")
-        if os.path.exists(tpath) and not self.opts and N == 1 << 20 and self.rows_total == 256 and rt.world == 1:
+        if os.path.exists(tpath) and not self.opts and N == 1 << 20 and self.rows_total == 256 and rt.shard == (0, 1):
             t = json.load(open(tpath))["per_kernel_class"].get(dom)
             if t:
                 traffic = t["hbm_bytes_per_launch"]
@@ -364,6 +370,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (smoke test of the RCCL path)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL; gloo with --emulate)")
+    ap.add_argument("--shard", default=None, metavar="R/G",
+                    help="diagnostic on ONE GPU: compute only the rows rank R of G would own (j = R mod G), with the "
+                         "--force-dist broadcast if given; `value` is then what G such ranks would deliver together")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
@@ -380,7 +389,7 @@ def main():
     kind, param, prec, label = CONFIGS[args.config]
     N = 1 << args.logn
     rows_total = args.rows * world if args.weak else args.rows
-    single = world == 1 and not args.no_cpu_baseline
+    single = world == 1 and not args.no_cpu_baseline and not args.shard
 
     head = measure(rt, args.config, args, rows_total, opts, want_cpu=single and rank == 0)
     workload = f"N=2^{args.logn} {label} {rows_total} scales"
@@ -397,7 +406,7 @@ def main():
                    "signal": "default_rng(1234).standard_normal(N)", "dt": 1.0,
                    "parallelism": (f"scale-sharded x{world}, 1 broadcast/step, backend {rt.backend}" if world > 1
                                    else "single GPU"),
-                   "plan_options": opts},
+                   "plan_options": opts, **({"shard_diagnostic": args.shard} if args.shard else {})},
         "roofline": head["roofline"],
     }
     for k in ("parity", "cpu_baseline"):
