@@ -694,12 +694,12 @@ void launch_pass_b_ct_lp(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, 
   if constexpr (!CONJ) {
     if (sp.base) {
       hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, true>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
-                         p->logN, W, long(ldw), long(ncols), sp);
+                         twn_of<T>(p), p->logN, W, long(ldw), long(ncols), sp);
       return;
     }
   }
   hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, false>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
-                     p->logN, W, long(ldw), long(ncols), sp);
+                     twn_of<T>(p), p->logN, W, long(ldw), long(ncols), sp);
 }
 
 template <typename T, int LOGK, bool CONJ>
@@ -712,10 +712,10 @@ void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int
       const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
       if (p->pass_b_prefetch == 4)
         hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 4>), dim3(ntiles / 4, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
-                           rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw), long(ncols));
+                           rows, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
       else
         hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 2>), dim3(ntiles / 2, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
-                           rows, tw_table<T>(p, LOGK), p->logN, W, long(ldw), long(ncols));
+                           rows, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
       return;
     }
   }
@@ -792,7 +792,7 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
                                  p->stream)) return;
       hipLaunchKernelGGL((k_pass_b<T, true>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
                          static_cast<const cplx<T>*>(p->Z), (const RowDesc*)nullptr, tw_table<T>(p, logK),
-                         logN, logK, logP - logK, o, long(p->N), long(p->N));
+                         twn_of<T>(p), logN, logK, logP - logK, o, long(p->N), long(p->N));
     });
     if (rc) return rc;
   }
@@ -867,8 +867,8 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       rc = timed_launch(p, KC_PASS_B, [&] {
         if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, sb)) return;
         hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sb,
-                           static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), logN, logK, logP - logK, W,
-                           long(ldw), long(ncols));
+                           static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), twn_of<T>(p), logN, logK,
+                           logP - logK, W, long(ldw), long(ncols));
       }, sb);
       if (rc) return rc;
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
@@ -1187,6 +1187,7 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
                        : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
 }
 
+extern "C++" {
 namespace {
 // Makes the slot built from `key` current and returns true, or picks the least recently used slot for a rebuild
 // (returns false; the caller builds p->rt->table and calls upload_row_table).  An empty key never matches.
@@ -1224,6 +1225,7 @@ std::vector<double> call_key(double kind, std::initializer_list<double> head, st
   return k;
 }
 }  // namespace
+}  // extern "C++"
 
 int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double param, double dt,
                        const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {

@@ -9,8 +9,10 @@
 //   k_small   N <= lmax            one workgroup FFT per row (also the forward FFT of the signal)
 //   k_direct  N <= 8               plain DFT (sizes below the radix-16 engine)
 //   k_narrow  band-limited rows    single pass: aliased K_j-point FFTs, N = K_j * R_j
-//   k_pass_a  wide rows, pass 1    column FFTs over k1 (k = q + K k1) + twiddle e^{2 pi i q r / N}
-//   k_pass_b  wide rows, pass 2    row FFTs over q, LDS transpose, store W[R m + r]
+//   k_pass_a  wide rows, pass 1    column FFTs over k1 (k = q + K k1)
+//   k_pass_b  wide rows, pass 2    twiddle e^{2 pi i q r / N} on load, row FFTs over q, LDS transpose, store W[R m + r]
+// (the inter-pass twiddle sits in pass B, which is memory bound, rather than in pass A, which is VALU / latency
+// bound: measured pass A -5 % fp64 / -16 % fp32, pass B +2 %)
 //   k_icwt    TC98 eq. 11 column reduction (wavelet.py:169-170)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -260,6 +262,18 @@ __global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict_
   out[orow * ldw + m] = mk<T>(T(sr), T(MODE != IN_SPECTRUM ? -si : si));
 }
 
+// slot e *= first * step^e  (the inter-pass twiddle e^{2 pi i q r / N} walked along one index)
+template <typename T>
+__device__ __forceinline__ void twiddle_slots(T (&re)[16], T (&im)[16], cplx<T> cur, const cplx<T> step) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const T x = re[e], y = im[e];
+    re[e] = x * cur.x - y * cur.y;
+    im[e] = x * cur.y + y * cur.x;
+    if (e < 15) cur = cmul<T>(cur, step);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_narrow: rows whose filter support is <= K = 2^logK bins.  N = K*R, n = R*m + r:
 //   W[R m + r] = sum_{q<K} ( Y[k(q)] e^{2 pi i k(q) r / N} ) e^{2 pi i q m / K},
@@ -322,7 +336,7 @@ k_narrow(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mot
 
 // ---------------------------------------------------------------------------------------------
 // k_pass_a: first pass of the two-pass transform, N = R*K, input bin k = q + K*k1:
-//   Z[r][q] = e^{2 pi i q r / N} sum_{k1<R} Y[q + K k1] e^{2 pi i k1 r / R}
+//   Z[r][q] = sum_{k1<R} Y[q + K k1] e^{2 pi i k1 r / R}      (the twiddle e^{2 pi i q r / N} is applied by pass B)
 // grid = (K/TQ, rows in chunk).  PLANES layout: lanes run along q (coalesced reads of xhat and
 // coalesced stores of Z rows).  MODE IN_REAL reads the zero-padded real signal instead.
 template <typename T, int MODE>
@@ -367,23 +381,20 @@ k_pass_a(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mother m
   }
   wg_ifft<T, true>(re, im, lds, g, tw);
   cplx<T>* z = Z + (long(blockIdx.y) << logN) + q;
-  cplx<T> cur = twn(unsigned(q) * unsigned(g.j));
-  const cplx<T> step = twn(unsigned(q) << logNT);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const long r = g.j + (e << logNT);
-    z[r << logK] = mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
-    cur = cmul<T>(cur, step);
+    z[r << logK] = mk<T>(re[e], im[e]);
   }
 }
 
-// k_pass_b: second pass: W[R m + r] = sum_{q<K} Z[r][q] e^{2 pi i q m / K}.
+// k_pass_b: second pass: W[R m + r] = sum_{q<K} (Z[r][q] e^{2 pi i q r / N}) e^{2 pi i q m / K}.
 // grid = (R/TB, rows in chunk).  ROWS layout for the FFT (coalesced reads of Z rows), then an LDS
 // transpose so that lanes run along r for the stores.  CONJ: store conj (forward transform).
 template <typename T, bool CONJ>
 __global__ void __launch_bounds__(CWT_MAX_THREADS)
 k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-         const cplx<T>* __restrict__ tw, int logN, int logK, int logTB, cplx<T>* __restrict__ W,
+         const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, int logK, int logTB, cplx<T>* __restrict__ W,
          long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
@@ -400,6 +411,7 @@ k_pass_b(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const cplx<T> v = z[e << logNT];
     re[e] = v.x; im[e] = v.y;
   }
+  twiddle_slots<T>(re, im, twn(unsigned(r0 + g.t) * unsigned(g.j)), twn(unsigned(r0 + g.t) << logNT));
   wg_ifft<T, false>(re, im, lds, g, tw);
 
   // transpose: element (t, m) -> linear index m*TB + t; thread reads back linear tid + c*blockDim
@@ -696,14 +708,8 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
   f.run(re, im, lds, tw);
   cplx<T>* z = Z + (long(blockIdx.y) << logN);
   const unsigned off = (unsigned(f.j) << logK) + q;
-  cplx<T> cur = twn(q * unsigned(f.j));
-  const cplx<T> step = twn(q << LOGNT);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    (z + (long(e * NT) << logK))[off] =
-        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
-    cur = cmul<T>(cur, step);
-  }
+  for (int e = 0; e < 16; ++e) (z + (long(e * NT) << logK))[off] = mk<T>(re[e], im[e]);
 }
 
 // Pass A for a row whose support spans only c <= C = 2^LOGC of the R = 2^LOGR bins k1 of every column q
@@ -712,7 +718,7 @@ k_pass_a_ct(const void* __restrict__ in, const RowDesc* __restrict__ rows, Mothe
 //   V[q'] = u_q[a(q')] e^{2 pi i (k1_base + a(q')) r' / R},  a(q') = (q' - k1_base) mod C,
 // exactly the band-limited form of k_narrow one level down.  8 columns x R2 residues per workgroup (the
 // same 8R points as the full pass A), log2 C instead of log2 R butterfly levels, and only 8 C filter
-// evaluations per workgroup.  Z layout and the trailing twiddle e^{2 pi i q r / N} are unchanged.
+// evaluations per workgroup.  Z layout is unchanged.
 template <typename T, int LOGR, int LOGP, int LOGC>
 __device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd,
                                                  const Mother& mo, const cplx<T>* __restrict__ tw_all,
@@ -758,15 +764,9 @@ __device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xha
   f.run(re, im, lds, tw_all + (C - 2));
   // slot e holds m' = j + e*NT  ->  r = R2 m' + r'
   const unsigned r0 = (unsigned(f.j) << LOGR2) + rp;
-  cplx<T> cur = twn(unsigned(q) * r0);
-  const cplx<T> step = twn((unsigned(q) << LOGNT) << LOGR2);
   const unsigned off = (r0 << logK) + unsigned(q);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    (z + ((long(e * NT) << LOGR2) << logK))[off] =
-        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
-    cur = cmul<T>(cur, step);
-  }
+  for (int e = 0; e < 16; ++e) (z + ((long(e * NT) << LOGR2) << logK))[off] = mk<T>(re[e], im[e]);
 }
 
 // Pass A of a chunk of wide rows: every workgroup branches once on its row's class (rd.logK: 0 = all
@@ -818,14 +818,8 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
   f.run(re, im, lds, tw_all + ((1 << LOGR) - 2));
   stamp<STAMP>(st, 2, false);
   const unsigned off = (unsigned(f.j) << logK) + q;
-  cplx<T> cur = twn(q * unsigned(f.j));
-  const cplx<T> step = twn(q << LOGNT);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    (z + (long(e * NT) << logK))[off] =
-        mk<T>(re[e] * cur.x - im[e] * cur.y, re[e] * cur.y + im[e] * cur.x);
-    cur = cmul<T>(cur, step);
-  }
+  for (int e = 0; e < 16; ++e) (z + (long(e * NT) << logK))[off] = mk<T>(re[e], im[e]);
   stamp<STAMP>(st, 3, false);
   stamp<STAMP>(st, 4, true);
 }
@@ -833,7 +827,8 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
 template <typename T, int LOGK, int LOGP, bool CONJ, bool STAMP = false>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_B_F64 : CWT_LB_PASS_B_F32))
 k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-            const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols, Stamps st) {
+            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols,
+            Stamps st) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, BD = 1 << (LOGP - 4);
@@ -853,6 +848,9 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     re[e] = v.x; im[e] = v.y;
   }
   stamp<STAMP>(st, 1, true);
+  twiddle_slots<T>(re, im, twn((r0 + unsigned(f.t)) * unsigned(f.j)), twn((r0 + unsigned(f.t)) << LOGNT));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { keep_here(re[e]); keep_here(im[e]); }   // twiddle done before the FFT's registers fill up
   f.run(re, im, lds, tw);
   stamp<STAMP>(st, 2, false);
 
@@ -868,7 +866,7 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 template <typename T, int LOGK, int LOGP, int NTILES>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 2 : 4))
 k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-               const cplx<T>* __restrict__ tw, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+               const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
@@ -900,6 +898,7 @@ k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 #pragma unroll
       for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; br[e] = v.x; bi[e] = v.y; }
     }
+    twiddle_slots<T>(ar, ai, twn((tile_r0(i) + unsigned(f.t)) * unsigned(f.j)), twn((tile_r0(i) + unsigned(f.t)) << LOGNT));
     f.run(ar, ai, lds, tw);
     transpose_store<T, LOGK, LOGP, false>(ar, ai, lds, f.t, f.j, wrow, logR, tile_r0(i), ncols);
     __syncthreads();                                     // LDS is reused by the next tile's FFT
@@ -909,6 +908,8 @@ k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; ar[e] = v.x; ai[e] = v.y; }
       }
+      twiddle_slots<T>(br, bi, twn((tile_r0(i + 1) + unsigned(f.t)) * unsigned(f.j)),
+                       twn((tile_r0(i + 1) + unsigned(f.t)) << LOGNT));
       f.run(br, bi, lds, tw);
       transpose_store<T, LOGK, LOGP, false>(br, bi, lds, f.t, f.j, wrow, logR, tile_r0(i + 1), ncols);
       __syncthreads();
