@@ -162,10 +162,11 @@ class Workload:
         self.plan.set_stream(rt.stream_handle())
 
     def compute(self, buf):
-        self.plan.forward_fft(buf.data_ptr(), self.N, self.xhat.data_ptr())
-        if len(self.sj):
-            self.plan.transform_rows(self.xhat.data_ptr(), self.kind, self.param, self.dt, self.sj, self.W.data_ptr(),
-                                     self.N, self.N)
+        if len(self.sj):   # forward FFT + every row of W in one call (wavelet.py:91-106)
+            self.plan.transform(buf.data_ptr(), self.N, self.kind, self.param, self.dt, self.sj, self.xhat.data_ptr(),
+                                self.W.data_ptr(), self.N, self.N)
+        else:
+            self.plan.forward_fft(buf.data_ptr(), self.N, self.xhat.data_ptr())
 
     def run_steps(self, count):
         """`count` steps.  With more than one rank the broadcast of step i+1 is issued (async, on RCCL's own
@@ -209,7 +210,7 @@ class Workload:
         units_by_class = {"small": split["small"] * N,
                           "narrow": (split["narrow"] - split["narrow_k2048"] - split["narrow_many"]) * N,
                           "narrow_big": split["narrow_k2048"] * N, "narrow_many": split["narrow_many"] * N,
-                          "pass_a": split["two_pass"] * N, "pass_b": split["two_pass"] * N}
+                          "pass_a": split["two_pass"] * N, "pass_b": split["two_pass"] * N, "ols": split["ols"] * N}
         kern = {name: {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
                 for name, (ms, cnt) in tm.items()}
         cand = [k for k in kern if units_by_class.get(k)]

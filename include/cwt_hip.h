@@ -83,6 +83,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "pass_b_small" 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
  *   "stamps"       n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
+ *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
+ *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
+ *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
@@ -114,6 +117,18 @@ int cwt_forward_fft(cwt_plan* plan, const void* x_dev, int64_t n0, void* xhat_de
 int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double param, double dt,
                        const double* scales_host, int nrows, void* W_dev, int64_t ldw,
                        int64_t ncols);
+
+/* The whole device-resident transform in one call -- wavelet.py:91 (forward FFT, written to xhat_dev: nfft complex, the
+ * caller needs it for the 5th return value of wavelet.py:123-124) and :94-106 (rows of W) -- for callers that still hold
+ * the signal.  Same results as cwt_forward_fft + cwt_transform_rows; knowing the real signal lets rows whose wavelet is
+ * compact in time (filter not clipped at the Nyquist bins, c_H*scale/dt <= a quarter of the workgroup tile) take the
+ * overlap-save form: per block of P - 2H output columns one P-point transform of x[n0-H .. n0+P-H) filtered by the same
+ * psi_ft sampled on the block's coarser frequency grid -- no N-point inverse transform, no intermediate in memory,
+ * contiguous stores.  The neglected tail of the wavelet is below 1e-17 (precision 64) / 5e-7 (32) of its L1 mass.
+ * x_dev: n0 reals.  Option "ols" = 0 turns that form off (then exactly the two calls above).                       */
+int cwt_transform(cwt_plan* plan, const void* x_dev, int64_t n0, int mother, double param, double dt,
+                  const double* scales_host, int nrows, void* xhat_dev, void* W_dev, int64_t ldw,
+                  int64_t ncols);
 
 /* The same two steps at a transform length n0 that is NOT a power of two -- what the reference computes when pyfftw is
  * installed: helpers.py:15-19 then passes n = len(signal), i.e. no zero padding and circular edges -- by Bluestein's
@@ -228,7 +243,8 @@ int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_
 /* Which kernel computed each row of the last transform call: codes[out_row] = kind*10000 + logK*100 + terms with
  * kind 0 = single-workgroup transform, 1 = band-limited single pass (K = 2^logK <= 1024, `terms` aliased bins per
  * input), 2 = band-limited single pass on 16384-point workgroups (K = 2048), 3 = two-pass (logK = log2 of the
- * pass-A column support class, 0 = full column).  *n = number of rows of the call; codes may be NULL.  The parity
+ * pass-A column support class, 0 = full column), 4 = overlap-save (K = 2^logK points per aliased block FFT).
+ * *n = number of rows of the call; codes may be NULL.  The parity
  * tests and bench.py use it to report the worst row per kernel class.                                          */
 int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
 /* Diagnostics: with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
@@ -237,11 +253,11 @@ int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
  * issue order, until n records are used.  Copies up to cap_records records to out_host, returns the number recorded
  * since the last call in *n_records and starts over.  Synchronises the stream.                                       */
 int cwt_plan_read_stamps(cwt_plan* plan, uint64_t* out_host, int64_t cap_records, int64_t* n_records);
-/* How the last cwt_transform_rows call split its rows: counts[0] = rows done by the single-workgroup
+/* How the last cwt_transform_rows / cwt_transform call split its rows: counts[0] = rows done by the single-workgroup
  * kernel, [1] = band-limited single pass with K <= 1024 and at most 4 aliased terms, [2] = two-pass, [3] = band-limited
  * single pass with K = 2048 (fp64, 16384-point workgroups), [4] = band-limited single pass with K = 1024 and 5..16
- * aliased terms. */
-int cwt_plan_last_split(cwt_plan* plan, int counts[5]);
+ * aliased terms, [5] = overlap-save. */
+int cwt_plan_last_split(cwt_plan* plan, int counts[6]);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ SYMBOLS = [
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_transform", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                C.c_int, _P, _P, C.c_int64, C.c_int64]),
     ("cwt_forward_fft_n", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows_n", C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                        C.c_int, _P, C.c_int64]),
@@ -186,6 +188,14 @@ class Plan:
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
 
     @_locked
+    def transform(self, x_dev: int, n0: int, mother: int, param: float, dt: float, scales, xhat_dev: int, W_dev: int,
+                  ldw: int, ncols: int):
+        """forward_fft + transform_rows in one call; the library may use the signal itself (overlap-save rows)."""
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_transform(self.h, _P(x_dev), n0, mother, float(param), float(dt), _dptr(s), s.size,
+                                              _P(xhat_dev), _P(W_dev), ldw, ncols))
+
+    @_locked
     def forward_fft_n(self, x_dev: int, n0: int, xhat_dev: int):
         """Forward transform at length n0 (not a power of two; this plan's nfft >= 2*n0 - 1)."""
         self.lib.check(self.lib.cwt_forward_fft_n(self.h, _P(x_dev), n0, _P(xhat_dev)))
@@ -311,6 +321,8 @@ class Plan:
                 out.append("two_pass/" + ("full" if logk == 0 else f"c{1 << logk}"))
             elif kind == 2:
                 out.append(f"narrow_k2048/t{terms}")
+            elif kind == 4:
+                out.append(f"ols/K{1 << logk}")
             else:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out
@@ -325,9 +337,10 @@ class Plan:
 
     @_locked
     def last_split(self):
-        c = (C.c_int * 5)()
+        c = (C.c_int * 6)()
         self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
-        return {"small": c[0], "narrow": c[1] + c[3] + c[4], "two_pass": c[2], "narrow_k2048": c[3], "narrow_many": c[4]}
+        return {"small": c[0], "narrow": c[1] + c[3] + c[4], "two_pass": c[2], "narrow_k2048": c[3], "narrow_many": c[4],
+                "ols": c[5]}
 
 
 class DeviceBuffer:

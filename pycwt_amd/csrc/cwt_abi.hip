@@ -41,9 +41,10 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_MANY, KC_NARROW_BIG,
-                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_COUNT };
+                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_COUNT };
 const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a",  "fwd_pass_b", "small",  "direct", "narrow",
-                                           "narrow_many", "narrow_big", "pass_a",     "pass_b", "icwt",   "elementwise"};
+                                           "narrow_many", "narrow_big", "pass_a",     "pass_b", "icwt",   "elementwise",
+                                           "ols_fwd", "ols"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -162,11 +163,14 @@ struct cwt_plan {
   int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
   int pass_b_prefetch = 0; // pass B as a 2- or 4-tile walk per workgroup with the next tile's loads in flight
   int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
+  int ols = 1;             // overlap-save rows (time-compact wavelets) when the call hands over the signal itself
+  int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
+  double ols_fwd_weight = 1.0;   // cost of one block spectrum in units of one row's block transform (class grouping)
   // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
   unsigned long long* stamps = nullptr;
   int64_t stamp_cap = 0, stamp_next = 0;
   // device resources
-  void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,4096; table of L starts at L-2
+  void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,16384; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
   int twn_shift = 0;
   void* weights_dev = nullptr;
@@ -175,6 +179,8 @@ struct cwt_plan {
   int weights_turn = 0;
   void* Z = nullptr;
   size_t z_bytes = 0;
+  void* xs = nullptr;       // block spectra of the overlap-save rows
+  size_t xs_bytes = 0;
   // buffers of cwt_execute_host
   void* hx = nullptr; size_t hx_bytes = 0;
   void* hxhat = nullptr; size_t hxhat_bytes = 0;
@@ -189,6 +195,9 @@ struct cwt_plan {
     std::vector<RowDesc> table;          // ordered: [small | narrow classes by logK | wide]
     std::vector<Group> narrow_groups;
     int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
+    int n_ols = 0, ols_first = 0;        // overlap-save rows (after the wide rows), sorted by halo class
+    OlsClasses ols_cls;
+    long ols_wgs = 0, ols_blocks = 0, ols_xs_elems = 0;
     RowDesc* rows_dev = nullptr;
     RowDesc* rows_pinned = nullptr;
     hipEvent_t uploaded = nullptr;
@@ -197,8 +206,8 @@ struct cwt_plan {
   RowTable slots[2];
   RowTable* rt = &slots[0];
   uint64_t tick = 0;
-  int split[5] = {0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
-                                    // band-limited K = 2048, band-limited K = 1024 with 5..16 terms
+  int split[6] = {0, 0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
+                                       // band-limited K = 2048, band-limited K = 1024 with 5..16 terms, overlap-save
   HostCopier* copier = nullptr;       // created by the first large device -> host copy
   // Bluestein state for transform lengths n0 that are not powers of two (this plan's N is then M >= 2 n0 - 1)
   int64_t bs_n0 = 0;
@@ -270,8 +279,8 @@ int timed_launch(cwt_plan* p, int cls, F&& launch) {
 template <typename T>
 int build_tables(cwt_plan* p) {
   const long double two_pi = 6.283185307179586476925286766559L;
-  std::vector<cplx<T>> all(8190);
-  for (int l = 1; l <= 12; ++l) {
+  std::vector<cplx<T>> all(32766);
+  for (int l = 1; l <= 14; ++l) {
     const size_t L = size_t(1) << l;
     for (size_t i = 0; i < L; ++i) {
       const long double ang = two_pi * (long double)i / (long double)L;
@@ -327,8 +336,40 @@ void profile_support(int mother, double p, double eps, double* f_lo, double* f_h
   }
 }
 
+// Overlap-save rows: the wavelet of scale s is treated as zero beyond |t| > c_H * s, c_H chosen so that the neglected
+// tail carries less than eps of the L1 mass of |psi| (the bound on the relative error of any output sample):
+//   Morlet, DOG m: |psi(eta)| = |He_m(eta)| exp(-eta^2/2) (m = 0 for Morlet) -- numerical quadrature;
+//   Paul m:        |psi(eta)| = (1 + eta^2)^(-(m+1)/2)   -- tail <= c^-m / m, total sqrt(pi) Gamma(m/2) / (2 Gamma((m+1)/2)).
+double time_halo_factor(int mother, double param, double eps) {
+  if (mother == MOTHER_PAUL) {
+    const double m = param;
+    const double total = 0.5 * std::sqrt(3.14159265358979323846) * std::tgamma(0.5 * m) / std::tgamma(0.5 * (m + 1.0));
+    return std::pow(eps * m * total, -1.0 / m);
+  }
+  const int m = mother == MOTHER_DOG ? int(std::lround(param)) : 0;
+  const double h = 1e-3;
+  const int n = 60000;
+  std::vector<double> g(n);
+  double total = 0;
+  for (int i = 0; i < n; ++i) {
+    const double eta = (i + 0.5) * h;
+    double h0 = 1.0, h1 = eta;                                  // probabilists' Hermite polynomials
+    for (int k = 1; k < m; ++k) { const double h2 = eta * h1 - k * h0; h0 = h1; h1 = h2; }
+    const double he = m == 0 ? 1.0 : h1;
+    g[i] = std::fabs(he) * std::exp(-0.5 * eta * eta);
+    total += g[i];
+  }
+  double tail = 0;
+  for (int i = n - 1; i >= 0; --i) {
+    tail += g[i];
+    if (tail > eps * total) return (i + 1) * h;
+  }
+  return h;
+}
+
 int two_pass_logk(const cwt_plan* p);
 int check_geometry(const cwt_plan* p);
+int grow(void** buf, size_t* have, size_t need, hipStream_t s);
 
 // Mother constant conj(c) with psi_ft(f) = c * profile(f)  (mothers.py:26-28, 118-122, 170-173)
 int mother_constant(int mother, double param, double* cre, double* cim) {
@@ -355,9 +396,12 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
 
 // Row table for W[j,:] = IFFT_N( spec_j[k] * (amp_j * profile(a_j * signed_bin(k))) ), spec_j = spec + j*spec_ld.
 // a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
+// ols_ncols > 0: the caller also has the real signal (cwt_transform): time-compact rows may take the overlap-save
+// form, their output blocks covering ols_ncols columns.
 int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
                     const double* amp_im, int64_t spec_ld, int nrows, const int* tab_klo = nullptr,
-                    const int* tab_nband = nullptr, int rows_per_signal = 0, int64_t tab_ld = -1) {
+                    const int* tab_nband = nullptr, int rows_per_signal = 0, int64_t tab_ld = -1,
+                    int64_t ols_ncols = 0) {
   const int64_t N = p->N;
   double f_lo = 0, f_hi = 0;
   if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
@@ -376,7 +420,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // K = 2048 single-pass rows: fp64 only, N >= 2^14 (a 16384-point workgroup tile must fit the row)
   const bool big_ok = p->use_ct && p->narrow_big && p->prec == 64 && narrow_cap >= 10 && logP == 13 &&
                       p->logN >= 14;
-  std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
+  // overlap-save rows: default geometry, at least 4 workgroup tiles per row, built-in mothers, one shared spectrum
+  const int ols_logp = p->prec == 64 ? 13 : 14;
+  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == ols_logp && p->logN >= ols_logp + 2 &&
+                      mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
+  const int ols_P = 1 << ols_logp;
+  const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
+  const double ols_ch = ols_ok ? time_halo_factor(mother, param, p->prec == 64 ? 1e-17 : 5e-7) : 0.0;
+  std::vector<RowDesc> narrow_rows, wide_rows, small_rows, ols_rows;
   for (int j = 0; j < nrows; ++j) {
     if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
     RowDesc rd;
@@ -388,6 +439,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
+    const bool unclipped = klo > -double(N / 2) && khi < double(N / 2 - 1);   // F_j vanishes at the Nyquist bins
     klo = std::max(klo, -double(N / 2));
     khi = std::min(khi, double(N / 2 - 1));
     if (mother == MOTHER_TABLE) { klo = tab_klo[j]; khi = klo + tab_nband[j] - 1; }
@@ -411,9 +463,33 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       const int t1 = (rd.nband + 1023) >> 10, t2 = (rd.nband + 2047) >> 11;
       const bool k1_ok = p->narrow && multi_ok && t1 <= p->narrow_terms;
       const bool k2_ok = p->narrow && big_ok && t2 <= p->big_terms;
+      // overlap-save form (see k_ols_ct): halo H = c_H * (scale in samples), a multiple of 64 so that whole
+      // wavefronts fall inside or outside the kept part of a block
+      int halo = 0;
+      if (ols_ok && unclipped && rd.nband > 0) {
+        const double s_samples = rd.a * double(N) / 6.283185307179586476925;
+        const double hh = std::ceil(ols_ch * s_samples / 64.0) * 64.0;
+        if (hh <= double(ols_hmax)) halo = std::max(64, int(hh));
+      }
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
+      } else if (halo) {
+        // the same filter sampled on the block's coarser frequency grid: bin k' of a P-point block is bin k' N / P
+        const double ab = rd.a * double(N >> ols_logp);
+        double kl = std::ceil(f_lo / ab), kh = std::floor(f_hi / ab);
+        if (mother == MOTHER_PAUL) kl = std::max(kl, 1.0);
+        kl = std::max(kl, -double(ols_P / 2));
+        kh = std::min(kh, double(ols_P / 2 - 1));
+        rd.a = ab;
+        rd.amp_re = amp_re[j] / double(ols_P);
+        rd.amp_im = amp_im[j] / double(ols_P);
+        rd.k_lo = int(kl);
+        rd.nband = kh >= kl ? int(kh - kl + 1) : 0;
+        if (rd.nband == 0) rd.k_lo = 0;
+        rd.logK = std::min(ols_logp, std::max(4, ilog2(std::max(rd.nband, 1))));
+        rd.nterms = halo / 64;                          // carried to the class grouping below
+        ols_rows.push_back(rd);
       } else if (k1_ok && (!k2_ok || t1 <= 3)) {
         rd.logK = 10;                                   // k_narrow_ct_all (<= 4 terms) / k_narrow_ct_many
         rd.nterms = t1;
@@ -455,6 +531,64 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   p->rt->n_small = int(small_rows.size());
   p->rt->n_narrow = int(narrow_rows.size());
   p->rt->n_wide = int(wide_rows.size());
+  // Overlap-save rows, grouped into at most OLS_MAX_CLASSES halo classes.  A class of rows i..j (sorted by halo) runs
+  // at the largest halo H_j: every block transform yields P - 2 H_j columns, and the class pays one block spectrum per
+  // block on top of its rows -> cost (rows + w) * P / (P - 2 H_j); dynamic programme over the distinct halos.
+  p->rt->ols_first = int(p->rt->table.size());
+  p->rt->n_ols = int(ols_rows.size());
+  p->rt->ols_cls.n = 0;
+  p->rt->ols_wgs = p->rt->ols_blocks = p->rt->ols_xs_elems = 0;
+  if (!ols_rows.empty()) {
+    std::stable_sort(ols_rows.begin(), ols_rows.end(),
+                     [](const RowDesc& x, const RowDesc& y) { return x.nterms < y.nterms; });
+    std::vector<int> hv, cnt;                                   // distinct halos (units of 64) and their row counts
+    for (const auto& r : ols_rows) {
+      if (hv.empty() || hv.back() != r.nterms) { hv.push_back(r.nterms); cnt.push_back(0); }
+      cnt.back()++;
+    }
+    const int nd = int(hv.size()), KC = OLS_MAX_CLASSES;
+    std::vector<int> pre(nd + 1, 0);
+    for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
+    auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
+      return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(ols_P) / double(ols_P - 128 * hv[j - 1]);
+    };
+    const double inf = 1e300;
+    std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
+    std::vector<std::vector<int>> from(KC + 1, std::vector<int>(nd + 1, -1));
+    dp[0][0] = 0;
+    for (int k = 1; k <= KC; ++k)
+      for (int j = 1; j <= nd; ++j)
+        for (int i = 0; i < j; ++i)
+          if (dp[k - 1][i] < inf && dp[k - 1][i] + cost(i, j) < dp[k][j]) { dp[k][j] = dp[k - 1][i] + cost(i, j); from[k][j] = i; }
+    int bestk = 1;
+    for (int k = 2; k <= KC; ++k) if (dp[k][nd] < dp[bestk][nd]) bestk = k;
+    std::vector<int> cuts;                                      // class boundaries in distinct-halo indices
+    for (int k = bestk, j = nd; k >= 1; --k) { cuts.push_back(j); j = from[k][j]; }
+    std::reverse(cuts.begin(), cuts.end());
+    OlsClasses& oc = p->rt->ols_cls;
+    oc.n = int(cuts.size());
+    int lo_d = 0;
+    long wg = 0, blk = 0, xs = 0;
+    const long stride = (ols_P / 2) + 8;
+    for (int c = 0; c < oc.n; ++c) {
+      const int hi_d = cuts[c], H = 64 * hv[hi_d - 1], L = ols_P - 2 * H;
+      OlsClass& k = oc.c[c];
+      k.halo = H;
+      k.nblocks = int((ols_ncols + L - 1) / L);
+      k.nrows = pre[hi_d] - pre[lo_d];
+      k.row_first = pre[lo_d];
+      k.wg_first = int(wg);
+      k.blk_first = int(blk);
+      k.xs_off = xs;
+      wg += long((k.nblocks + 7) / 8) * 8 * k.nrows;
+      blk += k.nblocks;
+      xs += long(k.nblocks) * stride;
+      lo_d = hi_d;
+    }
+    for (auto& r : ols_rows) r.nterms = 1;
+    p->rt->ols_wgs = wg; p->rt->ols_blocks = blk; p->rt->ols_xs_elems = xs;
+    p->rt->table.insert(p->rt->table.end(), ols_rows.begin(), ols_rows.end());
+  }
   return CWT_OK;
 }
 
@@ -466,7 +600,7 @@ void set_split(cwt_plan* p) {
     else if (g.nterms > 4) n_many += g.count;
   }
   p->split[0] = p->rt->n_small; p->split[1] = p->rt->n_narrow - n_big - n_many; p->split[2] = p->rt->n_wide;
-  p->split[3] = n_big; p->split[4] = n_many;
+  p->split[3] = n_big; p->split[4] = n_many; p->split[5] = p->rt->n_ols;
 }
 
 int chunk_rows_of(const cwt_plan* p) {
@@ -799,9 +933,34 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   return CWT_OK;
 }
 
+// Overlap-save rows (k_ols_fwd + k_ols_ct) of the current row table; x_dev = the real signal (n0 samples).
+template <typename T>
+int launch_ols(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols,
+               hipStream_t st) {
+  constexpr int LOGP = default_logp<T>();
+  const cwt_plan::RowTable* rt = p->rt;
+  int rc = grow(&p->xs, &p->xs_bytes, size_t(rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
+  if (rc) return rc;
+  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGP>), allow_big_lds(&k_ols_ct<T, LOGP>), true);
+  (void)once;
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  const dim3 block(1 << (LOGP - 4));
+  cplx<T>* xs = static_cast<cplx<T>*>(p->xs);
+  rc = timed_launch(p, KC_OLS_FWD, [&] {
+    hipLaunchKernelGGL((k_ols_fwd<T, LOGP>), dim3(unsigned(rt->ols_blocks)), block, lds, st, static_cast<const T*>(x_dev),
+                       long(n0), p->logN, rt->ols_cls, static_cast<const cplx<T>*>(p->tw_all), xs);
+  }, st);
+  if (rc) return rc;
+  return timed_launch(p, KC_OLS, [&] {
+    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(rt->ols_wgs)), block, lds, st, static_cast<const cplx<T>*>(xs),
+                       rt->rows_dev + rt->ols_first, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN,
+                       rt->ols_cls, W, long(ldw), long(ncols));
+  }, st);
+}
+
 template <typename T>
 int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, void* W_dev, int64_t ldw,
-              int64_t ncols) {
+              int64_t ncols, const void* x_dev = nullptr, int64_t n0 = 0) {
   const int logN = p->logN;
   const cplx<T>* xhat = static_cast<const cplx<T>*>(xhat_dev);
   cplx<T>* W = static_cast<cplx<T>*>(W_dev);
@@ -829,7 +988,9 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int logP = std::min(p->log_wg_points, logN);
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
-  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && p->rt->n_wide && p->rt->n_narrow;
+  if (p->rt->n_ols && !x_dev) return fail(CWT_EINVAL, "overlap-save rows need the signal");
+  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols) &&
+                           p->rt->n_narrow;
   if (side_narrow) {   // side stream 0 starts after the spectrum exists
     HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
     HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
@@ -873,6 +1034,18 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       if (rc) return rc;
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
+  }
+  if (p->rt->n_ols) {
+    if (p->overlap && p->rt->n_wide) {   // the pipelined two-pass chain lives on the side streams: join it first
+      const int chunk = balanced_chunk(p, p->rt->n_wide);
+      const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
+      if (nchunks > 1) {
+        HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
+        HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
+      }
+    }
+    rc = launch_ols<T>(p, x_dev, n0, mo, W, ldw, ncols, p->stream);
+    if (rc) return rc;
   }
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
   // tails) when "overlap_narrow" is set, else on the plan's own stream
@@ -1079,7 +1252,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->hx, p->hxhat, p->hW, p->stamps,
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->hx, p->hxhat, p->hW, p->stamps,
                   p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
@@ -1144,6 +1317,9 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
     }
   }
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
+  else if (k == "ols") p->ols = value != 0;
+  else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
+  else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);
@@ -1227,14 +1403,17 @@ std::vector<double> call_key(double kind, std::initializer_list<double> head, st
 }  // namespace
 }  // extern "C++"
 
-int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double param, double dt,
-                       const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
-  if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+extern "C++" {
+namespace {
+// Rows of W from the spectrum xhat_dev; x_dev != NULL: the real signal the spectrum came from (n0 samples), which lets
+// time-compact rows take the overlap-save form.
+int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, int64_t n0, int mother, double param,
+                          double dt, const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
-  HIPCHECK(hipSetDevice(p->device));
-  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows)}, {{scales, nrows}});
+  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), x_dev ? double(ncols) : 0.0},
+                                           {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
     int rc = mother_constant(mother, param, &cre, &cim);
@@ -1248,15 +1427,36 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
       ar[j] = norm * cre;
       ai[j] = norm * cim;
     }
-    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows);
+    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows, nullptr, nullptr, 0, -1,
+                         x_dev ? ncols : 0);
     if (!rc) rc = upload_row_table(p, key);
     if (rc) return rc;
   }
   set_split(p);
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
-  return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols)
-                       : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols);
+  return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
+                       : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+}
+}  // namespace
+}  // extern "C++"
+
+int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double param, double dt,
+                       const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
+  if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(p->device));
+  return transform_rows_common(p, xhat_dev, nullptr, 0, mother, param, dt, scales, nrows, W_dev, ldw, ncols);
+}
+
+int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double param, double dt,
+                  const double* scales, int nrows, void* xhat_dev, void* W_dev, int64_t ldw, int64_t ncols) {
+  if (!p || !x_dev || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
+  HIPCHECK(hipSetDevice(p->device));
+  int rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
+                         : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
+  if (rc) return rc;
+  return transform_rows_common(p, xhat_dev, x_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw, ncols);
 }
 
 int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int64_t xhat_ld, int mother,
@@ -1676,12 +1876,9 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!rc && W_host) rc = grow(&p->hW, &p->hW_bytes, size_t(nrows) * size_t(n0) * 2 * es, p->stream);
   if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(p->hx, x_host, size_t(n0) * es, hipMemcpyHostToDevice, p->stream));
-  rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
+  if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);
+  else rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
   if (rc) return rc;
-  if (W_host) {
-    rc = cwt_transform_rows(p, p->hxhat, mother, param, dt, scales, nrows, p->hW, n0, n0);
-    if (rc) return rc;
-  }
   if (xhat_host)
     HIPCHECK(hipMemcpyAsync(xhat_host, p->hxhat, size_t(p->N) * 2 * es, hipMemcpyDeviceToHost, p->stream));
   if (W_host) return copy_d2h(p, W_host, p->hW, size_t(nrows) * size_t(n0) * 2 * es);
@@ -1724,7 +1921,7 @@ int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
   if (!codes) return CWT_OK;
   for (int i = 0; i < total; ++i) {
     const RowDesc& rd = p->rt->table[i];
-    const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : 3;
+    const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : i < p->rt->ols_first ? 3 : 4;
     if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
   }
   return CWT_OK;
@@ -1741,9 +1938,9 @@ int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, i
   return CWT_OK;
 }
 
-int cwt_plan_last_split(cwt_plan* p, int counts[5]) {
+int cwt_plan_last_split(cwt_plan* p, int counts[6]) {
   if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
-  for (int i = 0; i < 5; ++i) counts[i] = p->split[i];
+  for (int i = 0; i < 6; ++i) counts[i] = p->split[i];
   return CWT_OK;
 }
 

@@ -917,6 +917,183 @@ k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
   }
 }
 
+// =============================================================================================
+// Overlap-save rows (k_ols_fwd, k_ols_ct): wide-band rows whose wavelet is COMPACT IN TIME.
+//
+// W[j, n] = sum_m x[m] h_j[(n - m) mod N], h_j = IFFT_N(F_j).  Where F_j is not clipped at the Nyquist bins, h_j is the
+// sampled wavelet psi((t)/s)/s up to the filter-support threshold, negligible beyond |t| > H = c_H * s/dt samples
+// (c_H from the mother's tail mass, `time_halo_factor`).  For an output block [n0, n0 + L), L = P - 2H, take the P
+// input samples x[n0 - H .. n0 + L + H) (indices mod N, zero beyond the signal as the padded reference has them):
+//   y = IFFT_P( FFT_P(x_block) * G_j ),  G_j[k'] = F_j[k' N / P]   (decimating the spectrum = wrapping h_j to period P)
+// and y[H .. H + L) = W[j, n0 .. n0 + L) up to the neglected tail: no intermediate in memory, no N-point transform,
+// fully contiguous stores.  FFT_P(x_block) is shared by every row of a halo class: k_ols_fwd writes the half
+// spectra X_b[0 .. P/2] (x is real) of all blocks of all classes once per transform, k_ols_ct reads them through L2
+// (all rows of one block run on the same XCD).  The block transform is itself band limited (support B P / N bins),
+// so it runs as P/K aliased K-point FFTs exactly like k_narrow one level down, on ONE workgroup tile: TB = P / K
+// residues x K points = the whole block, n_local = thread + e * P/16.
+struct OlsClass {
+  int wg_first;    // first workgroup of this class in the k_ols_ct launch (multiple of 8)
+  int blk_first;   // first workgroup (= block) of this class in the k_ols_fwd launch
+  int nblocks;     // output blocks of L = P - 2*halo columns
+  int nrows;       // rows of this class
+  int row_first;   // their first entry in the row table passed to k_ols_ct
+  int halo;        // H (multiple of 64)
+  long xs_off;     // element offset of this class's block spectra (nblocks x (P/2 + 8) complex)
+};
+constexpr int OLS_MAX_CLASSES = 16;
+struct OlsClasses {
+  OlsClass c[OLS_MAX_CLASSES];
+  int n;
+};
+template <int LOGP> constexpr int ols_stride() { return (1 << (LOGP - 1)) + 8; }   // complex elements per block spectrum
+
+// X_b[k] * G_row[k] for signed block bin ks, X_b[-k] = conj(X_b[k]) (0 outside the row's band)
+template <typename T>
+__device__ __forceinline__ cplx<T> ols_bin(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo, int ks) {
+  const unsigned d = unsigned(ks - rd.k_lo);
+  if (d >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
+  cplx<T> x = xb[ks < 0 ? -ks : ks];
+  if (ks < 0) x.y = -x.y;
+  const T g = profile<T>(mo, T(rd.a) * T(ks));
+  const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
+  return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
+}
+
+// Half spectra of the input blocks: one workgroup = one block of one halo class.
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all,
+          cplx<T>* __restrict__ xs) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int P = 1 << LOGP, NT = P >> 4;
+  using F = ct::Fft<T, LOGP, 0, false>;
+  int c = 0;
+  while (c + 1 < cls.n && int(blockIdx.x) >= cls.c[c + 1].blk_first) ++c;
+  const int blk = int(blockIdx.x) - cls.c[c].blk_first, H = cls.c[c].halo, L = P - 2 * H;
+  const long nmask = (1L << logN) - 1;
+  const long first = long(blk) * L - H;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long n = (first + f.j + e * NT) & nmask;
+    re[e] = n < n0 ? x[n] : T(0);
+    im[e] = T(0);
+  }
+  f.run(re, im, lds, tw_all + (P - 2));
+  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGP>();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[f.j + e * NT] = mk<T>(re[e], -im[e]);      // forward = conj(inverse) for real input
+  if (f.j == 0) out[P / 2] = mk<T>(re[8], -im[8]);
+}
+
+// Block transform with K = P: every thread filters its own 16 bins (rows whose block support exceeds P/2 bins).
+template <typename T, int LOGP>
+__device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
+                                              const cplx<T>* __restrict__ tw_all, cplx<T>* __restrict__ wout, int H,
+                                              int nlim, T* lds) {
+  constexpr int P = 1 << LOGP, NT = P >> 4;
+  using F = ct::Fft<T, LOGP, 0, false>;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> v = ols_bin<T>(xb, rd, mo, signed_bin(f.j + e * NT, P));
+    re[e] = v.x; im[e] = v.y;
+  }
+  f.run(re, im, lds, tw_all + (P - 2));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int nl = f.j + e * NT - H;
+    if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+  }
+}
+
+// Block transform for a block support <= K = 2^LOGK < P bins: TB = P / K aliased K-point FFTs (residue r = lane index
+// t, n_local = TB m + t), inputs Z_r[q] = Y[k(q)] e^{2 pi i k(q) r / P} with the filtered band Y built once in LDS.
+template <typename T, int LOGK, int LOGP>
+__device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
+                                              const cplx<T>* __restrict__ tw_all, const TwN<T>& twn, int logN,
+                                              cplx<T>* __restrict__ wout, int H, int nlim, T* lds) {
+  constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, NT = K >> 4, P = 1 << LOGP, BD = 1 << (LOGP - 4);
+  using F = ct::Fft<T, LOGK, LOGTB, true>;
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTB) - 1);
+  f.j = threadIdx.x >> LOGTB;
+  const unsigned r = unsigned(f.t);
+  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
+  for (int q = threadIdx.x; q < K; q += BD) {
+    const int dq = (q - rd.k_lo) & (K - 1);
+    ytile[q] = ols_bin<T>(xb, rd, mo, rd.k_lo + dq);
+  }
+  __syncthreads();
+  const int sh = logN - LOGP;
+  const unsigned pm = unsigned(P - 1);
+  const cplx<T> step = twn(((unsigned(NT) * r) & pm) << sh);
+  const cplx<T> stepw = cmul<T>(step, twn(((0u - (r << LOGK)) & pm) << sh));
+  int d = (f.j - rd.k_lo) & (K - 1);
+  cplx<T> cur = twn(((unsigned(rd.k_lo + d) * r) & pm) << sh);
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> y = ytile[f.j + e * NT];
+    re[e] = y.x * cur.x - y.y * cur.y;
+    im[e] = y.x * cur.y + y.y * cur.x;
+    const int dn = (d + NT) & (K - 1);
+    cur = cmul<T>(cur, dn < d ? stepw : step);
+    d = dn;
+  }
+  __syncthreads();                                       // the band tile aliases the exchange buffer
+  f.run(re, im, lds, tw_all + (K - 2));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int nl = int(threadIdx.x) + e * BD - H;        // n_local = TB (j + e NT) + t = thread + e P/16
+    if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+  }
+}
+
+// All overlap-save rows of a transform in one launch: 1-D grid, class c owns workgroups [wg_first, next wg_first);
+// inside a class the 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of a block back to back, so that
+// a block spectrum is fetched into one L2 once and read there by every row.
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
+k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mother mo,
+         const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, OlsClasses cls, cplx<T>* __restrict__ W, long ldw,
+         long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int P = 1 << LOGP;
+  int c = 0;
+  while (c + 1 < cls.n && int(blockIdx.x) >= cls.c[c + 1].wg_first) ++c;
+  const unsigned local = blockIdx.x - unsigned(cls.c[c].wg_first);
+  const unsigned seq = local >> 3, nr = unsigned(cls.c[c].nrows);
+  const unsigned blk = (seq / nr) * 8u + (local & 7u);
+  if (blk >= unsigned(cls.c[c].nblocks)) return;
+  const RowDesc rd = rows[cls.c[c].row_first + int(seq % nr)];
+  const int H = cls.c[c].halo, L = P - 2 * H;
+  const cplx<T>* xb = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGP>();
+  const long col0 = long(blk) * L;
+  const long left = ncols - col0;
+  const int nlim = left < L ? int(left) : L;
+  cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
+#define CWT_OLS_CASE(LK)                                                                            \
+  case LK:                                                                                           \
+    if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP>(xb, rd, mo, tw_all, twn, logN, wout, H, nlim, lds); \
+    else ols_full_body<T, LOGP>(xb, rd, mo, tw_all, wout, H, nlim, lds);                            \
+    break;
+  switch (rd.logK) {
+    CWT_OLS_CASE(4) CWT_OLS_CASE(5) CWT_OLS_CASE(6) CWT_OLS_CASE(7) CWT_OLS_CASE(8) CWT_OLS_CASE(9)
+    CWT_OLS_CASE(10) CWT_OLS_CASE(11) CWT_OLS_CASE(12) CWT_OLS_CASE(13)
+    default: ols_full_body<T, LOGP>(xb, rd, mo, tw_all, wout, H, nlim, lds); break;
+  }
+#undef CWT_OLS_CASE
+}
+
 // ---------------------------------------------------------------------------------------------
 // Element-wise helpers of the coherence path (pycwt/wavelet.py:499-514, mothers.py:97-102).
 // All matrices are rows x ld, row-major, n < ncols valid.

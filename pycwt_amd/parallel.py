@@ -51,6 +51,15 @@ class HipEngine:
             self.plan.transform_rows_batch(xhat.data_ptr(), xhat.shape[0], xhat.shape[1], kind, param, dt, sj,
                                            W.data_ptr(), W.shape[-1], ncols)
 
+    def transform(self, x, n0, xhat, kind, param, dt, sj, W, ncols):
+        """forward + rows; for one signal in ONE C call (cwt_transform), which lets the library use the signal itself
+        for time-compact rows (overlap-save)."""
+        if x.dim() == 1:
+            self.plan.transform(x.data_ptr(), n0, kind, param, dt, sj, xhat.data_ptr(), W.data_ptr(), W.shape[-1], ncols)
+        else:
+            self.forward(x, n0, xhat)
+            self.rows(xhat, kind, param, dt, sj, W, ncols)
+
     def icwt_partial(self, W, sj, out):
         self.plan.icwt_reduce(W.data_ptr(), W.shape[1], W.shape[1], sj, 1.0, out.data_ptr())
 
@@ -104,9 +113,12 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
         engine = HipEngine(N, precision, max(1, mine.size * nbatch), device.index or 0, device.type == "cuda")
     xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
-    engine.forward(x, n0, xhat)
-    if mine.size:
-        engine.rows(xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+    if mine.size and hasattr(engine, "transform"):
+        engine.transform(x, n0, xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+    else:
+        engine.forward(x, n0, xhat)
+        if mine.size:
+            engine.rows(xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
     return W, mine, sj, freqs, coi
 
 

@@ -292,8 +292,7 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     try:
         with plan.lock:
             xd.upload(plan, np.ascontiguousarray(signal, dtype=plan.real))
-            plan.forward_fft(xd.ptr, n0, xh.ptr)
-            plan.transform_rows(xh.ptr, kind, param, dt, sj, Wd.ptr, n0, n0)
+            plan.transform(xd.ptr, n0, kind, param, dt, sj, xh.ptr, Wd.ptr, n0, n0)
             xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
     except Exception:
         Wd.free()
@@ -537,8 +536,7 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
             W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
             for x, W in ((x1, W1), (x2, W2)):
                 xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
-                plan.forward_fft(xd.ptr, n0, xh.ptr)
-                plan.transform_rows(xh.ptr, kind, param, dt, sj, W.ptr, n0, n0)
+                plan.transform(xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, n0, n0)
             P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
             plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
             spec = alloc(rows * N * 2 * es)

@@ -459,7 +459,7 @@ def _download_rows(plan, buf, lo, cnt, ld, dtype):
 @pytest.mark.parametrize("name,prec", [("morlet", 64), ("paul", 32), ("dog", 32)])
 def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, prec):
     """BASELINE configs 2 and 3 exactly as bench.py times them -- N = 2^20, all 256 rows, device resident, through
-    cwt_forward_fft + cwt_transform_rows -- with EVERY row compared with the oracle (pycwt/wavelet.py:91-106
+    cwt_transform (forward FFT + rows, overlap-save rows included) -- with EVERY row compared with the oracle (pycwt/wavelet.py:91-106
     restated), in slabs of 16 rows.  Prints the worst row per kernel class.  Rows the reference turns into NaN
     (Paul: 161 of 256, wavelet.py:111-115) are computed too and must be finite; they have no reference value."""
     N, rows = 1 << 20, 256
@@ -474,10 +474,10 @@ def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, 
     xd, xh = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 2 * x.itemsize)
     Wd = _hip.DeviceBuffer(rows * N * 2 * x.itemsize)
     xd.upload(plan, x)
-    plan.forward_fft(xd.ptr, N, xh.ptr)
-    plan.transform_rows(xh.ptr, kind, param, 1.0, sj, Wd.ptr, N, N)
+    plan.transform(xd.ptr, N, kind, param, 1.0, sj, xh.ptr, Wd.ptr, N, N)
     classes = plan.row_classes()
     assert len(classes) == rows
+    assert any(c.startswith("ols/") for c in classes)
     dropped = orc.dropped_rows(sj, 1.0, m)
     worst, checked = {}, 0
     for lo in range(0, rows, 16):

@@ -141,7 +141,7 @@ def test_pass_a_classes_at_full_size(emu_library, kind, param, scales):
     m = orc.Mother(kind, param)
     sj = np.array(scales)
     ref = orc.cwt_rows(x, 1.0, sj, m)[:, :x.size]
-    for opts in ({"narrow_big": 0}, {"narrow_big": 0, "band_pass_a": 0}):
+    for opts in ({"narrow_big": 0, "ols": 0}, {"narrow_big": 0, "band_pass_a": 0, "ols": 0}):
         plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options=opts)
         W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
         assert plan.last_split()["two_pass"] == len(scales)
@@ -170,7 +170,7 @@ def test_k2048_single_pass_rows(emu_library, kind, param):
     ref = orc.cwt_rows(x, 1.0, sj, m)
     splits = {}
     for big in (1, 0):
-        plan = _hip.Plan(N, 64, max_rows=8, lib=emu_library, options={"narrow_big": big})
+        plan = _hip.Plan(N, 64, max_rows=8, lib=emu_library, options={"narrow_big": big, "ols": 0})
         W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
         splits[big] = plan.last_split()
         plan.close()
@@ -187,7 +187,7 @@ def test_two_pass_layout_and_tile_options(emu_library, opts, prec):
     x = np.random.default_rng(11).standard_normal(N - 1)
     m = orc.Mother(orc.MORLET, 6)
     sj = 2.9 * N / np.array([60000.0, 30000.0, 20000.0, 9000.0, 2500.0])
-    o = dict(opts, narrow_big=0, narrow_terms=1)
+    o = dict(opts, narrow_big=0, narrow_terms=1, ols=0)
     plan = _hip.Plan(N, prec, max_rows=8, lib=emu_library, options=o)
     W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
     assert plan.last_split()["two_pass"] >= 4
@@ -199,7 +199,7 @@ def test_two_pass_layout_and_tile_options(emu_library, opts, prec):
 def test_phase_stamps_are_recorded_per_workgroup(emu_library):
     N = 1 << 16
     x = np.random.default_rng(11).standard_normal(N)
-    plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options={"stamps": 4096, "narrow_big": 0, "narrow_terms": 1})
+    plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options={"stamps": 4096, "narrow_big": 0, "narrow_terms": 1, "ols": 0})
     W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, [3.0, 9.0], want_xhat=False)
     n, rec = plan.read_stamps(4096)
     # pass A: 2 rows x N/4096 half-size tiles, pass B: 2 rows x N/8192 tiles
@@ -252,7 +252,7 @@ def test_many_aliased_terms_in_lds_batches(emu_library, prec, opts, expect, kind
     m = orc.Mother(kind, param)
     c = 2.9 if kind == orc.MORLET else 2.5
     sj = c * N / np.array([5000.0, 7000.0, 9000.0, 12500.0, 15500.0, 3000.0])
-    plan = _hip.Plan(N, prec, max_rows=8, lib=emu_library, options=opts)
+    plan = _hip.Plan(N, prec, max_rows=8, lib=emu_library, options=dict(opts, ols=0))
     W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
     split, classes = plan.last_split(), plan.row_classes()
     plan.close()
@@ -270,9 +270,83 @@ def test_pass_b_with_prefetched_tiles(emu_library, tiles, prec):
     x = np.random.default_rng(17).standard_normal(N - 5)
     m = orc.Mother(orc.MORLET, 6)
     sj = 2.9 * N / np.array([250000.0, 40000.0, 17000.0])
-    plan = _hip.Plan(N, prec, max_rows=4, lib=emu_library, options={"pass_b_prefetch": tiles})
+    plan = _hip.Plan(N, prec, max_rows=4, lib=emu_library, options={"pass_b_prefetch": tiles, "ols": 0})
     W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
     assert plan.last_split()["two_pass"] == 3
     plan.close()
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m)[:, :x.size])
     assert per_row.max() < TOL[prec], per_row
+
+
+# ---- overlap-save rows (k_ols_fwd / k_ols_ct): time-compact wavelets, cwt_transform / cwt_execute_host only ----
+@pytest.mark.parametrize("kind,param,prec,N,n0,rows", [
+    (orc.MORLET, 6, 64, 1 << 16, 1 << 16, 64),        # circular edges (n0 = N), K = 8192 (full block) .. 256
+    (orc.MORLET, 6, 64, 1 << 15, 30000, 24),          # smallest transform that takes the form, ragged last block
+    (orc.MORLET, 6, 32, 1 << 16, 50001, 40),
+    (orc.PAUL, 4, 32, 1 << 16, 40001, 48),            # polynomial tails: c_H = 29.5
+    (orc.DOG, 2, 32, 1 << 16, 65000, 48),             # two-sided spectrum, K = 16384 (full block)
+    (orc.DOG, 2, 64, 1 << 16, 50000, 40),
+    (orc.DOG, 1, 64, 1 << 15, 32768, 20),             # odd order: imaginary mother constant
+])
+def test_overlap_save_rows(emu_library, kind, param, prec, N, n0, rows):
+    """Rows whose filter is not clipped at Nyquist and whose wavelet fits a quarter tile in time are computed block
+    by block from the signal itself; same values as the N-point transform of the spectrum (oracle) and as the library's
+    own two-pass / band-limited kernels (option ols = 0)."""
+    x = np.random.default_rng(21).standard_normal(n0)
+    m = orc.Mother(kind, param)
+    sj = grid(n0, 1.0, m, rows)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
+    out = {}
+    for ols in (1, 0):
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"ols": ols})
+        W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+        out[ols] = (W, plan.last_split(), plan.row_classes())
+        plan.close()
+    W, split, classes = out[1]
+    assert split["ols"] >= 4 and out[0][1]["ols"] == 0, (split, out[0][1])
+    assert split["ols"] + split["narrow"] + split["two_pass"] == len(sj)
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < TOL[prec], (per_row.argmax(), per_row.max(), classes[per_row.argmax()])
+    mine = [i for i, c in enumerate(classes) if c.startswith("ols/")]
+    same, _ = row_errors(W[mine], out[0][0][mine])
+    assert same.max() < TOL[prec]
+
+
+def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
+    """cwt_transform_rows (spectrum only) never takes the form; cwt_transform does; ols_max_halo and ols_fwd_weight steer
+    which rows and how many halo classes."""
+    from pycwt_amd._hip import DeviceBuffer
+    N = 1 << 16
+    x = np.random.default_rng(2).standard_normal(N)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 48)
+    ref = orc.cwt_rows(x, 1.0, sj, m)
+    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library)
+    xd, xh, Wd = DeviceBuffer(x.nbytes, lib=emu_library), DeviceBuffer(16 * N, lib=emu_library), DeviceBuffer(16 * N * len(sj), lib=emu_library)
+    xd.upload(plan, x)
+    plan.forward_fft(xd.ptr, N, xh.ptr)
+    plan.transform_rows(xh.ptr, orc.MORLET, 6, 1.0, sj, Wd.ptr, N, N)
+    assert plan.last_split()["ols"] == 0
+    W0 = Wd.download(plan, (len(sj), N), np.complex128)
+    plan.transform(xd.ptr, N, orc.MORLET, 6, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+    n_all = plan.last_split()["ols"]
+    assert n_all > 0
+    W1 = Wd.download(plan, (len(sj), N), np.complex128)
+    xhat = xh.download(plan, (N,), np.complex128)
+    assert np.abs(xhat - np.fft.fft(x)).max() / np.abs(xhat).max() < 1e-13
+    for W in (W0, W1):
+        assert row_errors(W, ref)[0].max() < 1e-12
+    plan.set_option("ols_max_halo", 256)
+    plan.transform(xd.ptr, N, orc.MORLET, 6, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+    assert 0 < plan.last_split()["ols"] < n_all
+    assert row_errors(Wd.download(plan, (len(sj), N), np.complex128), ref)[0].max() < 1e-12
+    with pytest.raises(_hip.HipError):
+        plan.set_option("ols_max_halo", 100)
+    plan.set_option("ols_max_halo", 0)
+    plan.set_option("ols_fwd_weight", 1000)            # block spectra priced at 10 rows: few, wide classes
+    plan.transform(xd.ptr, N, orc.MORLET, 6, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+    assert plan.last_split()["ols"] == n_all
+    assert row_errors(Wd.download(plan, (len(sj), N), np.complex128), ref)[0].max() < 1e-12
+    for b in (xd, xh, Wd):
+        b.free()
+    plan.close()

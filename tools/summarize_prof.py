@@ -28,6 +28,10 @@ def klass(name):
         return "narrow_big"
     if name.startswith("k_narrow_ct_many"):
         return "narrow_many"
+    if name.startswith("k_ols_fwd"):
+        return "ols_fwd"
+    if name.startswith("k_ols_ct"):
+        return "ols"
     for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
         if name.startswith(k):
             args = name[name.find("<") + 1:name.rfind(">")].split(", ") if "<" in name else []
