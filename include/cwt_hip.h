@@ -85,6 +85,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
  *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
+ *   "ols_big"      0 = no double-length blocks (precision 64: rows with halo >= "ols_big_min_halo", default 1536, and a
+ *                  block support <= 1/8 tile use blocks of two workgroup tiles)
+ *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
+ *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
@@ -243,7 +247,8 @@ int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_
 /* Which kernel computed each row of the last transform call: codes[out_row] = kind*10000 + logK*100 + terms with
  * kind 0 = single-workgroup transform, 1 = band-limited single pass (K = 2^logK <= 1024, `terms` aliased bins per
  * input), 2 = band-limited single pass on 16384-point workgroups (K = 2048), 3 = two-pass (logK = log2 of the
- * pass-A column support class, 0 = full column), 4 = overlap-save (K = 2^logK points per aliased block FFT).
+ * pass-A column support class, 0 = full column), 4 = overlap-save (K = 2^logK points per aliased block FFT, `terms` =
+ * workgroups per block: 1 = blocks of one workgroup tile, 2 = blocks of two).
  * *n = number of rows of the call; codes may be NULL.  The parity
  * tests and bench.py use it to report the worst row per kernel class.                                          */
 int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);

@@ -322,7 +322,7 @@ class Plan:
             elif kind == 2:
                 out.append(f"narrow_k2048/t{terms}")
             elif kind == 4:
-                out.append(f"ols/K{1 << logk}")
+                out.append(("ols/K" if terms == 1 else f"ols{terms}/K") + str(1 << logk))
             else:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out

@@ -164,6 +164,11 @@ struct cwt_plan {
   int pass_b_prefetch = 0; // pass B as a 2- or 4-tile walk per workgroup with the next tile's loads in flight
   int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
   int ols = 1;             // overlap-save rows (time-compact wavelets) when the call hands over the signal itself
+  int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
+  int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
+  int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
+  int ols_big = 1;         // fp64: blocks of 2P points for rows with long halos (two workgroups per block)
+  int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
   int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
   double ols_fwd_weight = 1.0;   // cost of one block spectrum in units of one row's block transform (class grouping)
   // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
@@ -197,7 +202,8 @@ struct cwt_plan {
     int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
     int n_ols = 0, ols_first = 0;        // overlap-save rows (after the wide rows), sorted by halo class
     OlsClasses ols_cls;
-    long ols_wgs = 0, ols_blocks = 0, ols_xs_elems = 0;
+    long ols_wgs = 0, ols_xs_elems = 0;
+    long ols_fwd_blocks[2] = {0, 0};     // blocks of P points, blocks of 2P points
     RowDesc* rows_dev = nullptr;
     RowDesc* rows_pinned = nullptr;
     hipEvent_t uploaded = nullptr;
@@ -218,6 +224,7 @@ struct cwt_plan {
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
+  hipEvent_t ev_ols = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
@@ -426,7 +433,12 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
                       mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
+  const bool ols_big = ols_ok && p->ols_big && p->prec == 64 && p->logN >= ols_logp + 3;   // blocks of 2P points
   const double ols_ch = ols_ok ? time_halo_factor(mother, param, p->prec == 64 ? 1e-17 : 5e-7) : 0.0;
+  // "not clipped at Nyquist": the profile at the Nyquist bins is below this fraction of its peak (the jump there is what
+  // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
+  double fc_lo = 0, fc_hi = 0;
+  if (ols_ok) profile_support(mother, param, p->prec == 64 ? 1e-14 : 1e-8, &fc_lo, &fc_hi);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows, ols_rows;
   for (int j = 0; j < nrows; ++j) {
     if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
@@ -439,7 +451,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
-    const bool unclipped = klo > -double(N / 2) && khi < double(N / 2 - 1);   // F_j vanishes at the Nyquist bins
+    const bool unclipped = ols_ok && std::ceil(fc_lo / rd.a) > -double(N / 2) &&      // F_j vanishes at the Nyquist bins
+                           std::floor(fc_hi / rd.a) < double(N / 2 - 1);
     klo = std::max(klo, -double(N / 2));
     khi = std::min(khi, double(N / 2 - 1));
     if (mother == MOTHER_TABLE) { klo = tab_klo[j]; khi = klo + tab_nband[j] - 1; }
@@ -464,30 +477,58 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       const bool k1_ok = p->narrow && multi_ok && t1 <= p->narrow_terms;
       const bool k2_ok = p->narrow && big_ok && t2 <= p->big_terms;
       // overlap-save form (see k_ols_ct): halo H = c_H * (scale in samples), a multiple of 64 so that whole
-      // wavefronts fall inside or outside the kept part of a block
-      int halo = 0;
+      // wavefronts fall inside or outside the kept part of a block.  Block length P_b = P, or 2P (fp64) where that
+      // keeps a larger fraction of every block transform and the stores stay >= 128-byte segments (K <= P/8).
+      int halo = 0, lb = ols_logp;
       if (ols_ok && unclipped && rd.nband > 0) {
         const double s_samples = rd.a * double(N) / 6.283185307179586476925;
         const double hh = std::ceil(ols_ch * s_samples / 64.0) * 64.0;
-        if (hh <= double(ols_hmax)) halo = std::max(64, int(hh));
+        if (hh <= double(ols_hmax) * (ols_big ? 2.0 : 1.0)) halo = std::max(64, int(hh));
+      }
+      RowDesc od = rd;
+      if (halo) {
+        // the same filter sampled on the block's coarser frequency grid: bin k' of a P_b-point block is bin k' N / P_b.
+        // K-point block FFTs, K >= the support; the band start is moved down to a multiple of K/16 (the bins added
+        // lie below the support threshold) so that the aliased index wraps at the same slot in every thread
+        auto describe = [&](int logb, RowDesc& o) {
+          const int Pb = 1 << logb;
+          const double ab = rd.a * double(N >> logb);
+          double kl = std::ceil(f_lo / ab), kh = std::floor(f_hi / ab);
+          if (mother == MOTHER_PAUL) kl = std::max(kl, 1.0);
+          kl = std::max(kl, -double(Pb / 2));
+          kh = std::min(kh, double(Pb / 2 - 1));
+          o.a = ab;
+          o.amp_re = amp_re[j] / double(Pb);
+          o.amp_im = amp_im[j] / double(Pb);
+          o.k_lo = int(kl);
+          o.nband = kh >= kl ? int(kh - kl + 1) : 0;
+          if (o.nband == 0) o.k_lo = 0;
+          for (o.logK = std::max(4, ilog2(std::max(o.nband, 1))); o.logK < ols_logp; ++o.logK) {
+            const int nt = 1 << (o.logK - 4);
+            const int lo = o.k_lo - (((o.k_lo % nt) + nt) % nt);
+            if (o.nband + (o.k_lo - lo) <= (1 << o.logK) && lo >= -(Pb / 2)) {
+              o.nband += o.k_lo - lo;
+              o.k_lo = lo;
+              break;
+            }
+          }
+        };
+        RowDesc big = rd;
+        bool big_fits = false;
+        if (ols_big && halo >= p->ols_big_min_halo) {
+          describe(ols_logp + 1, big);
+          big_fits = big.logK <= ols_logp - 3;
+        }
+        if (big_fits) { od = big; lb = ols_logp + 1; }
+        else if (halo <= ols_hmax) describe(ols_logp, od);
+        else halo = 0;
       }
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
       } else if (halo) {
-        // the same filter sampled on the block's coarser frequency grid: bin k' of a P-point block is bin k' N / P
-        const double ab = rd.a * double(N >> ols_logp);
-        double kl = std::ceil(f_lo / ab), kh = std::floor(f_hi / ab);
-        if (mother == MOTHER_PAUL) kl = std::max(kl, 1.0);
-        kl = std::max(kl, -double(ols_P / 2));
-        kh = std::min(kh, double(ols_P / 2 - 1));
-        rd.a = ab;
-        rd.amp_re = amp_re[j] / double(ols_P);
-        rd.amp_im = amp_im[j] / double(ols_P);
-        rd.k_lo = int(kl);
-        rd.nband = kh >= kl ? int(kh - kl + 1) : 0;
-        if (rd.nband == 0) rd.k_lo = 0;
-        rd.logK = std::min(ols_logp, std::max(4, ilog2(std::max(rd.nband, 1))));
+        rd = od;
+        rd.tab_off = lb;                                // carried to the class grouping below (unused by these rows)
         rd.nterms = halo / 64;                          // carried to the class grouping below
         ols_rows.push_back(rd);
       } else if (k1_ok && (!k2_ok || t1 <= 3)) {
@@ -537,56 +578,71 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   p->rt->ols_first = int(p->rt->table.size());
   p->rt->n_ols = int(ols_rows.size());
   p->rt->ols_cls.n = 0;
-  p->rt->ols_wgs = p->rt->ols_blocks = p->rt->ols_xs_elems = 0;
+  p->rt->ols_wgs = p->rt->ols_xs_elems = 0;
+  p->rt->ols_fwd_blocks[0] = p->rt->ols_fwd_blocks[1] = 0;
   if (!ols_rows.empty()) {
-    std::stable_sort(ols_rows.begin(), ols_rows.end(),
-                     [](const RowDesc& x, const RowDesc& y) { return x.nterms < y.nterms; });
-    std::vector<int> hv, cnt;                                   // distinct halos (units of 64) and their row counts
-    for (const auto& r : ols_rows) {
-      if (hv.empty() || hv.back() != r.nterms) { hv.push_back(r.nterms); cnt.push_back(0); }
-      cnt.back()++;
-    }
-    const int nd = int(hv.size()), KC = OLS_MAX_CLASSES;
-    std::vector<int> pre(nd + 1, 0);
-    for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
-    auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
-      return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(ols_P) / double(ols_P - 128 * hv[j - 1]);
-    };
-    const double inf = 1e300;
-    std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
-    std::vector<std::vector<int>> from(KC + 1, std::vector<int>(nd + 1, -1));
-    dp[0][0] = 0;
-    for (int k = 1; k <= KC; ++k)
-      for (int j = 1; j <= nd; ++j)
-        for (int i = 0; i < j; ++i)
-          if (dp[k - 1][i] < inf && dp[k - 1][i] + cost(i, j) < dp[k][j]) { dp[k][j] = dp[k - 1][i] + cost(i, j); from[k][j] = i; }
-    int bestk = 1;
-    for (int k = 2; k <= KC; ++k) if (dp[k][nd] < dp[bestk][nd]) bestk = k;
-    std::vector<int> cuts;                                      // class boundaries in distinct-halo indices
-    for (int k = bestk, j = nd; k >= 1; --k) { cuts.push_back(j); j = from[k][j]; }
-    std::reverse(cuts.begin(), cuts.end());
+    // by block length, then halo
+    std::stable_sort(ols_rows.begin(), ols_rows.end(), [](const RowDesc& x, const RowDesc& y) {
+      return x.tab_off != y.tab_off ? x.tab_off < y.tab_off : x.nterms < y.nterms;
+    });
     OlsClasses& oc = p->rt->ols_cls;
-    oc.n = int(cuts.size());
-    int lo_d = 0;
-    long wg = 0, blk = 0, xs = 0;
-    const long stride = (ols_P / 2) + 8;
-    for (int c = 0; c < oc.n; ++c) {
-      const int hi_d = cuts[c], H = 64 * hv[hi_d - 1], L = ols_P - 2 * H;
-      OlsClass& k = oc.c[c];
-      k.halo = H;
-      k.nblocks = int((ols_ncols + L - 1) / L);
-      k.nrows = pre[hi_d] - pre[lo_d];
-      k.row_first = pre[lo_d];
-      k.wg_first = int(wg);
-      k.blk_first = int(blk);
-      k.xs_off = xs;
-      wg += long((k.nblocks + 7) / 8) * 8 * k.nrows;
-      blk += k.nblocks;
-      xs += long(k.nblocks) * stride;
-      lo_d = hi_d;
+    oc.n = 0;
+    long wg = 0, xs = 0;
+    int row0 = 0;
+    for (int lb = ols_logp; lb <= ols_logp + 1; ++lb) {
+      int nr = 0;
+      while (row0 + nr < int(ols_rows.size()) && ols_rows[row0 + nr].tab_off == lb) ++nr;
+      if (!nr) continue;
+      const int Pb = 1 << lb, G = 1 << (lb - ols_logp);
+      std::vector<int> hv, cnt;                                   // distinct halos (units of 64) and their row counts
+      for (int i = row0; i < row0 + nr; ++i) {
+        if (hv.empty() || hv.back() != ols_rows[i].nterms) { hv.push_back(ols_rows[i].nterms); cnt.push_back(0); }
+        cnt.back()++;
+      }
+      const int nd = int(hv.size()), KC = OLS_MAX_CLASSES / 2;
+      std::vector<int> pre(nd + 1, 0);
+      for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
+      auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
+        return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(Pb) / double(Pb - 128 * hv[j - 1]);
+      };
+      const double inf = 1e300;
+      std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
+      std::vector<std::vector<int>> from(KC + 1, std::vector<int>(nd + 1, -1));
+      dp[0][0] = 0;
+      for (int k = 1; k <= KC; ++k)
+        for (int j = 1; j <= nd; ++j)
+          for (int i = 0; i < j; ++i)
+            if (dp[k - 1][i] < inf && dp[k - 1][i] + cost(i, j) < dp[k][j]) { dp[k][j] = dp[k - 1][i] + cost(i, j); from[k][j] = i; }
+      int bestk = 1;
+      for (int k = 2; k <= KC; ++k) if (dp[k][nd] < dp[bestk][nd]) bestk = k;
+      std::vector<int> cuts;                                      // class boundaries in distinct-halo indices
+      for (int k = bestk, j = nd; k >= 1; --k) { cuts.push_back(j); j = from[k][j]; }
+      std::reverse(cuts.begin(), cuts.end());
+      int lo_d = 0;
+      long blk = 0;
+      const long stride = (Pb / 2) + 8;
+      for (size_t ci = 0; ci < cuts.size(); ++ci) {
+        const int hi_d = cuts[ci], H = 64 * hv[hi_d - 1], L = Pb - 2 * H;
+        OlsClass& k = oc.c[oc.n++];
+        k.halo = H;
+        k.logb = lb;
+        k.pad_ = 0;
+        k.nblocks = int((ols_ncols + L - 1) / L);
+        k.nrows = pre[hi_d] - pre[lo_d];
+        k.row_first = row0 + pre[lo_d];
+        k.wg_first = int(wg);
+        k.blk_first = int(blk);
+        k.xs_off = xs;
+        wg += long((k.nblocks + 7) / 8) * 8 * k.nrows * G;
+        blk += k.nblocks;
+        xs += long(k.nblocks) * stride;
+        lo_d = hi_d;
+      }
+      p->rt->ols_fwd_blocks[lb - ols_logp] = blk;
+      row0 += nr;
     }
-    for (auto& r : ols_rows) r.nterms = 1;
-    p->rt->ols_wgs = wg; p->rt->ols_blocks = blk; p->rt->ols_xs_elems = xs;
+    for (auto& r : ols_rows) { r.nterms = 1 << (int(r.tab_off) - ols_logp); r.tab_off = 0; }   // nterms = workgroups per block
+    p->rt->ols_wgs = wg; p->rt->ols_xs_elems = xs;
     p->rt->table.insert(p->rt->table.end(), ols_rows.begin(), ols_rows.end());
   }
   return CWT_OK;
@@ -933,28 +989,48 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   return CWT_OK;
 }
 
-// Overlap-save rows (k_ols_fwd + k_ols_ct) of the current row table; x_dev = the real signal (n0 samples).
+// Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd) ...
+template <typename T, int LOGB>
+int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, hipStream_t st) {
+  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGB>), true);
+  (void)once;
+  const size_t lds = ((size_t(1) << LOGB) + (size_t(1) << (LOGB - 4))) * sizeof(T);
+  return timed_launch(p, KC_OLS_FWD, [&] {
+    hipLaunchKernelGGL((k_ols_fwd<T, LOGB>), dim3(unsigned(blocks)), dim3(1 << (LOGB - 4)), lds, st,
+                       static_cast<const T*>(x_dev), long(n0), p->logN, p->rt->ols_cls,
+                       static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xs));
+  }, st);
+}
 template <typename T>
-int launch_ols(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols,
-               hipStream_t st) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
+  constexpr int LOGP = default_logp<T>();
+  int rc = CWT_OK;
+  if (p->rt->ols_fwd_blocks[0]) rc = launch_ols_fwd_b<T, LOGP>(p, x_dev, n0, p->rt->ols_fwd_blocks[0], st);
+  if constexpr (sizeof(T) == 8) {
+    if (!rc && p->rt->ols_fwd_blocks[1]) rc = launch_ols_fwd_b<T, LOGP + 1>(p, x_dev, n0, p->rt->ols_fwd_blocks[1], st);
+  }
+  return rc;
+}
+// ... and the rows themselves (k_ols_ct)
+template <typename T>
+int launch_ols_rows(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
   const cwt_plan::RowTable* rt = p->rt;
-  int rc = grow(&p->xs, &p->xs_bytes, size_t(rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
-  if (rc) return rc;
-  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGP>), allow_big_lds(&k_ols_ct<T, LOGP>), true);
+  static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_MORLET>), allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_PAUL>),
+                            allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_DOG>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
   const dim3 block(1 << (LOGP - 4));
-  cplx<T>* xs = static_cast<cplx<T>*>(p->xs);
-  rc = timed_launch(p, KC_OLS_FWD, [&] {
-    hipLaunchKernelGGL((k_ols_fwd<T, LOGP>), dim3(unsigned(rt->ols_blocks)), block, lds, st, static_cast<const T*>(x_dev),
-                       long(n0), p->logN, rt->ols_cls, static_cast<const cplx<T>*>(p->tw_all), xs);
-  }, st);
-  if (rc) return rc;
+  const cplx<T>* xs = static_cast<const cplx<T>*>(p->xs);
   return timed_launch(p, KC_OLS, [&] {
-    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(rt->ols_wgs)), block, lds, st, static_cast<const cplx<T>*>(xs),
-                       rt->rows_dev + rt->ols_first, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN,
-                       rt->ols_cls, W, long(ldw), long(ncols));
+#define CWT_OLS_LAUNCH(MK)                                                                                             \
+    hipLaunchKernelGGL((k_ols_ct<T, LOGP, MK>), dim3(unsigned(rt->ols_wgs)), block, lds, st, xs,                          \
+                       rt->rows_dev + rt->ols_first, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN,   \
+                       rt->ols_cls, W, long(ldw), long(ncols))
+    if (mo.kind == MOTHER_MORLET) CWT_OLS_LAUNCH(MOTHER_MORLET);
+    else if (mo.kind == MOTHER_PAUL) CWT_OLS_LAUNCH(MOTHER_PAUL);
+    else CWT_OLS_LAUNCH(MOTHER_DOG);
+#undef CWT_OLS_LAUNCH
   }, st);
 }
 
@@ -991,9 +1067,20 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   if (p->rt->n_ols && !x_dev) return fail(CWT_EINVAL, "overlap-save rows need the signal");
   const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols) &&
                            p->rt->n_narrow;
-  if (side_narrow) {   // side stream 0 starts after the spectrum exists
-    HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
-    HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
+  // block spectra of the overlap-save rows: beside the two-pass chain on side stream 1 (they only need the signal)
+  const bool ols_early = p->rt->n_ols && p->ols_launched;       // already queued on side stream 1 by cwt_transform
+  const bool ols_side = p->rt->n_ols && !ols_early && p->ols_side && !p->profile && !p->overlap && p->rt->n_wide;
+  if (p->rt->n_ols && !ols_early) {
+    rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
+    if (rc) return rc;
+  }
+  if (side_narrow || ols_side) HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
+  if (side_narrow) HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));   // starts after the spectrum exists
+  if (ols_side) {
+    HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
+    rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
   if (p->rt->n_wide) {
     const int logK = two_pass_logk(p), logR = logN - logK;
@@ -1035,7 +1122,9 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
   }
-  if (p->rt->n_ols) {
+  if (ols_early) {
+    HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
+  } else if (p->rt->n_ols) {
     if (p->overlap && p->rt->n_wide) {   // the pipelined two-pass chain lives on the side streams: join it first
       const int chunk = balanced_chunk(p, p->rt->n_wide);
       const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
@@ -1044,7 +1133,9 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
         HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
       }
     }
-    rc = launch_ols<T>(p, x_dev, n0, mo, W, ldw, ncols, p->stream);
+    if (ols_side) HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
+    else rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream);
+    if (!rc) rc = launch_ols_rows<T>(p, mo, W, ldw, ncols, p->stream);
     if (rc) return rc;
   }
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
@@ -1220,6 +1311,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   for (auto& t : p->slots) {
     if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "row table allocation failed");
@@ -1249,6 +1341,7 @@ int cwt_plan_destroy(cwt_plan* p) {
     if (p->ev_b[i]) (void)hipEventDestroy(p->ev_b[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
   if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
@@ -1318,6 +1411,10 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   }
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
   else if (k == "ols") p->ols = value != 0;
+  else if (k == "ols_side") p->ols_side = value != 0;
+  else if (k == "ols_big") p->ols_big = value != 0;
+  else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
+  else if (k == "ols_early") p->ols_early = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
@@ -1405,14 +1502,12 @@ std::vector<double> call_key(double kind, std::initializer_list<double> head, st
 
 extern "C++" {
 namespace {
-// Rows of W from the spectrum xhat_dev; x_dev != NULL: the real signal the spectrum came from (n0 samples), which lets
-// time-compact rows take the overlap-save form.
-int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, int64_t n0, int mother, double param,
-                          double dt, const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
+int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, double dt, const double* scales,
+                       int nrows, int64_t ldw, int64_t ncols) {
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
-  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), x_dev ? double(ncols) : 0.0},
+  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), have_signal ? double(ncols) : 0.0},
                                            {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -1428,15 +1523,46 @@ int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, 
       ai[j] = norm * cim;
     }
     rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows, nullptr, nullptr, 0, -1,
-                         x_dev ? ncols : 0);
+                         have_signal ? ncols : 0);
     if (!rc) rc = upload_row_table(p, key);
     if (rc) return rc;
   }
   set_split(p);
+  return CWT_OK;
+}
+
+Mother mother_of(int mother, double param) {
   Mother mo;
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
+  return mo;
+}
+
+// Rows of W from the spectrum xhat_dev; x_dev != NULL: the real signal the spectrum came from (n0 samples), which lets
+// time-compact rows take the overlap-save form.
+int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, int64_t n0, int mother, double param,
+                          double dt, const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
+  int rc = prepare_rows_table(p, x_dev != nullptr, mother, param, dt, scales, nrows, ldw, ncols);
+  if (rc) return rc;
+  const Mother mo = mother_of(mother, param);
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+}
+
+// The overlap-save rows need the signal only: cwt_transform queues them on side stream 1 BEFORE the forward FFT, so
+// that they run beside it and beside the two-pass chain; rows_impl then skips them and joins the stream at its end.
+template <typename T>
+int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, void* W_dev, int64_t ldw,
+                     int64_t ncols) {
+  int rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
+  if (rc) return rc;
+  HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
+  HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
+  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);
+  if (!rc) rc = launch_ols_rows<T>(p, mo, static_cast<cplx<T>*>(W_dev), ldw, ncols, p->side[1]);
+  if (rc) return rc;
+  HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
+  p->ols_launched = 1;
+  return CWT_OK;
 }
 }  // namespace
 }  // extern "C++"
@@ -1453,10 +1579,21 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   if (!p || !x_dev || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  int rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
-                         : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
+  int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
-  return transform_rows_common(p, xhat_dev, x_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw, ncols);
+  const Mother mo = mother_of(mother, param);
+  p->ols_launched = 0;
+  if (p->rt->n_ols && p->ols_early && !p->profile && !p->overlap) {
+    rc = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, mo, W_dev, ldw, ncols)
+                       : launch_ols_early<float>(p, x_dev, n0, mo, W_dev, ldw, ncols);
+    if (rc) return rc;
+  }
+  rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
+                     : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
+  if (!rc) rc = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
+                              : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+  p->ols_launched = 0;
+  return rc;
 }
 
 int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int64_t xhat_ld, int mother,

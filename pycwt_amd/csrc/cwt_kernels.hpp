@@ -22,6 +22,9 @@
 #ifndef CWT_MAX_THREADS
 #define CWT_MAX_THREADS 1024
 #endif
+#ifndef CWT_OLS_ABLATE
+#define CWT_OLS_ABLATE 0      // timing-only ablations of the overlap-save band kernel (tuning builds): 1 = no FFT, 2 = no stores
+#endif
 // Minimum resident waves per SIMD the compiler must allow for (second __launch_bounds__ argument, i.e. the VGPR
 // budget: 4 -> 128, 5 -> 96, 6 -> 80, 8 -> 64 registers) of the compile-time kernels, per precision.  Measured
 // defaults; override with -D for tuning runs.
@@ -930,15 +933,19 @@ k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
 // spectra X_b[0 .. P/2] (x is real) of all blocks of all classes once per transform, k_ols_ct reads them through L2
 // (all rows of one block run on the same XCD).  The block transform is itself band limited (support B P / N bins),
 // so it runs as P/K aliased K-point FFTs exactly like k_narrow one level down, on ONE workgroup tile: TB = P / K
-// residues x K points = the whole block, n_local = thread + e * P/16.
+// residues x K points = the whole block, n_local = thread + e * P/16.  Rows with long halos and narrow block
+// supports use blocks of P_b = 2P points instead (the kept fraction (P_b - 2H) / P_b rises): the P_b / K residues of
+// a block are split over P_b / P workgroups, each storing TB-element segments (n_local = (P_b / K) m + r).
 struct OlsClass {
   int wg_first;    // first workgroup of this class in the k_ols_ct launch (multiple of 8)
-  int blk_first;   // first workgroup (= block) of this class in the k_ols_fwd launch
-  int nblocks;     // output blocks of L = P - 2*halo columns
+  int blk_first;   // first workgroup (= block) of this class in the k_ols_fwd<T, logb> launch
+  int nblocks;     // output blocks of L = 2^logb - 2*halo columns
   int nrows;       // rows of this class
   int row_first;   // their first entry in the row table passed to k_ols_ct
   int halo;        // H (multiple of 64)
-  long xs_off;     // element offset of this class's block spectra (nblocks x (P/2 + 8) complex)
+  int logb;        // log2 of the block length P_b >= P (workgroup tile): P_b / P workgroups share one block transform
+  int pad_;
+  long xs_off;     // element offset of this class's block spectra (nblocks x (P_b/2 + 8) complex)
 };
 constexpr int OLS_MAX_CLASSES = 16;
 struct OlsClasses {
@@ -947,29 +954,49 @@ struct OlsClasses {
 };
 template <int LOGP> constexpr int ols_stride() { return (1 << (LOGP - 1)) + 8; }   // complex elements per block spectrum
 
-// X_b[k] * G_row[k] for signed block bin ks, X_b[-k] = conj(X_b[k]) (0 outside the row's band)
+// profile() with the mother known at compile time (straight-line code: the loads of neighbouring bins can be
+// scheduled together)
+template <typename T, int MK>
+__device__ __forceinline__ T profile_k(const Mother& mo, T f) {
+  if constexpr (MK == MOTHER_MORLET) {
+    const T d = f - T(mo.p);
+    return exp_(T(-0.5) * d * d);
+  } else if constexpr (MK == MOTHER_PAUL) {
+    return f > T(0) ? ipow<T>(f, mo.m) * exp_(-f) : T(0);
+  } else {
+    return ipow<T>(f, mo.m) * exp_(T(-0.5) * f * f);
+  }
+}
+
+// X_b[k] for signed block bin ks from the stored half spectrum (X_b[-k] = conj X_b[k]); bins outside the row's band
+// read entry 0 (any valid address) and are zeroed by ols_apply
 template <typename T>
-__device__ __forceinline__ cplx<T> ols_bin(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo, int ks) {
-  const unsigned d = unsigned(ks - rd.k_lo);
-  if (d >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
-  cplx<T> x = xb[ks < 0 ? -ks : ks];
+__device__ __forceinline__ cplx<T> ols_load(const cplx<T>* __restrict__ xb, const RowDesc& rd, int ks) {
+  const bool in = unsigned(ks - rd.k_lo) < unsigned(rd.nband);
+  return xb[in ? (ks < 0 ? -ks : ks) : 0];
+}
+// x * G_row[ks]
+template <typename T, int MK>
+__device__ __forceinline__ cplx<T> ols_apply(cplx<T> x, const RowDesc& rd, const Mother& mo, int ks) {
+  if (unsigned(ks - rd.k_lo) >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
   if (ks < 0) x.y = -x.y;
-  const T g = profile<T>(mo, T(rd.a) * T(ks));
+  const T g = profile_k<T, MK>(mo, T(rd.a) * T(ks));
   const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
   return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
 }
 
-// Half spectra of the input blocks: one workgroup = one block of one halo class.
-template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+// Half spectra of the input blocks of the classes with block length 2^LOGB: one workgroup = one block.
+template <typename T, int LOGB>
+__global__ void __launch_bounds__(1 << (LOGB - 4), (LOGB - 4 >= 10 ? 4 : 4))
 k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all,
           cplx<T>* __restrict__ xs) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
-  constexpr int P = 1 << LOGP, NT = P >> 4;
-  using F = ct::Fft<T, LOGP, 0, false>;
+  constexpr int P = 1 << LOGB, NT = P >> 4;
+  using F = ct::Fft<T, LOGB, 0, false>;
   int c = 0;
-  while (c + 1 < cls.n && int(blockIdx.x) >= cls.c[c + 1].blk_first) ++c;
+  for (int i = 0; i < cls.n; ++i)
+    if (cls.c[i].logb == LOGB && int(blockIdx.x) >= cls.c[i].blk_first) c = i;
   const int blk = int(blockIdx.x) - cls.c[c].blk_first, H = cls.c[c].halo, L = P - 2 * H;
   const long nmask = (1L << logN) - 1;
   const long first = long(blk) * L - H;
@@ -984,14 +1011,14 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
     im[e] = T(0);
   }
   f.run(re, im, lds, tw_all + (P - 2));
-  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGP>();
+  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGB>();
 #pragma unroll
   for (int e = 0; e < 8; ++e) out[f.j + e * NT] = mk<T>(re[e], -im[e]);      // forward = conj(inverse) for real input
   if (f.j == 0) out[P / 2] = mk<T>(re[8], -im[8]);
 }
 
 // Block transform with K = P: every thread filters its own 16 bins (rows whose block support exceeds P/2 bins).
-template <typename T, int LOGP>
+template <typename T, int LOGP, int MK>
 __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
                                               const cplx<T>* __restrict__ tw_all, cplx<T>* __restrict__ wout, int H,
                                               int nlim, T* lds) {
@@ -1002,8 +1029,13 @@ __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, co
   f.j = threadIdx.x;
   T re[16], im[16];
 #pragma unroll
+  for (int e = 0; e < 16; ++e) {                          // all loads first, then the arithmetic
+    const cplx<T> v = ols_load<T>(xb, rd, signed_bin(f.j + e * NT, P));
+    re[e] = v.x; im[e] = v.y;
+  }
+#pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const cplx<T> v = ols_bin<T>(xb, rd, mo, signed_bin(f.j + e * NT, P));
+    const cplx<T> v = ols_apply<T, MK>(mk<T>(re[e], im[e]), rd, mo, signed_bin(f.j + e * NT, P));
     re[e] = v.x; im[e] = v.y;
   }
   f.run(re, im, lds, tw_all + (P - 2));
@@ -1016,51 +1048,69 @@ __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, co
 
 // Block transform for a block support <= K = 2^LOGK < P bins: TB = P / K aliased K-point FFTs (residue r = lane index
 // t, n_local = TB m + t), inputs Z_r[q] = Y[k(q)] e^{2 pi i k(q) r / P} with the filtered band Y built once in LDS.
-template <typename T, int LOGK, int LOGP>
+// The host aligns the band start k_lo to a multiple of K/16, so that k(q) = k_lo + ((q - k_lo) mod K) wraps between
+// the same two slots for every thread: slots e >= ew = 16 - ((-k_lo mod K) / NT) carry an extra e^{-2 pi i K r / P}.
+template <typename T, int LOGK, int LOGP, int MK>
 __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
                                               const cplx<T>* __restrict__ tw_all, const TwN<T>& twn, int logN,
-                                              cplx<T>* __restrict__ wout, int H, int nlim, T* lds) {
-  constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, NT = K >> 4, P = 1 << LOGP, BD = 1 << (LOGP - 4);
-  using F = ct::Fft<T, LOGK, LOGTB, true>;
+                                              cplx<T>* __restrict__ wout, int H, int nlim, T* lds, int logx, unsigned g) {
+  // logx = log2(P_b / P), g < P_b / P: this workgroup's residues are r = g TB + t of the P_b / K of the block
+  constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, NT = K >> 4, BD = 1 << (LOGP - 4);
+  using F = ct::Fft<T, LOGK, LOGTB, true, (LOGTB <= 2)>;
   F f;
   f.t = threadIdx.x & ((1 << LOGTB) - 1);
   f.j = threadIdx.x >> LOGTB;
-  const unsigned r = unsigned(f.t);
+  const unsigned r = (g << LOGTB) + unsigned(f.t);
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
-  for (int q = threadIdx.x; q < K; q += BD) {
-    const int dq = (q - rd.k_lo) & (K - 1);
-    ytile[q] = ols_bin<T>(xb, rd, mo, rd.k_lo + dq);
+  constexpr int NQ = K > BD ? K / BD : 1;                 // band bins per thread
+  cplx<T> yv[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = int(threadIdx.x) + i * BD;
+    if (q < K) yv[i] = ols_load<T>(xb, rd, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = int(threadIdx.x) + i * BD;
+    if (q < K) ytile[q] = ols_apply<T, MK>(yv[i], rd, mo, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
   }
   __syncthreads();
-  const int sh = logN - LOGP;
-  const unsigned pm = unsigned(P - 1);
+  const int sh = logN - LOGP - logx;
+  const unsigned pm = (1u << (LOGP + logx)) - 1u;
   const cplx<T> step = twn(((unsigned(NT) * r) & pm) << sh);
-  const cplx<T> stepw = cmul<T>(step, twn(((0u - (r << LOGK)) & pm) << sh));
-  int d = (f.j - rd.k_lo) & (K - 1);
-  cplx<T> cur = twn(((unsigned(rd.k_lo + d) * r) & pm) << sh);
+  const cplx<T> rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
+  const int c0 = ((0 - rd.k_lo) & (K - 1)) >> (LOGK - 4);               // (-k_lo mod K) / NT, k_lo = 0 mod NT
+  const int ew = 16 - c0;                                               // uniform: first slot after the wrap
+  cplx<T> cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
   T re[16], im[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const cplx<T> y = ytile[f.j + e * NT];
     re[e] = y.x * cur.x - y.y * cur.y;
     im[e] = y.x * cur.y + y.y * cur.x;
-    const int dn = (d + NT) & (K - 1);
-    cur = cmul<T>(cur, dn < d ? stepw : step);
-    d = dn;
+    if (e < 15) cur = cmul<T>(cur, step);
+    if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
   }
   __syncthreads();                                       // the band tile aliases the exchange buffer
+#if CWT_OLS_ABLATE != 1
   f.run(re, im, lds, tw_all + (K - 2));
+#endif
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int nl = int(threadIdx.x) + e * BD - H;        // n_local = TB (j + e NT) + t = thread + e P/16
+    // n_local = (P_b / K) (j + e NT) + r; with P_b = P this is thread + e P/16
+    const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
+#if CWT_OLS_ABLATE == 2
+    if (nl >= 0 && nl < nlim && re[e] == T(-1.2345e-300)) store_w<T>(wout + nl, re[e], im[e]);
+#else
     if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+#endif
   }
 }
 
 // All overlap-save rows of a transform in one launch: 1-D grid, class c owns workgroups [wg_first, next wg_first);
 // inside a class the 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of a block back to back, so that
 // a block spectrum is fetched into one L2 once and read there by every row.
-template <typename T, int LOGP>
+template <typename T, int LOGP, int MK>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
 k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mother mo,
          const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, OlsClasses cls, cplx<T>* __restrict__ W, long ldw,
@@ -1071,25 +1121,27 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mothe
   int c = 0;
   while (c + 1 < cls.n && int(blockIdx.x) >= cls.c[c + 1].wg_first) ++c;
   const unsigned local = blockIdx.x - unsigned(cls.c[c].wg_first);
-  const unsigned seq = local >> 3, nr = unsigned(cls.c[c].nrows);
+  const int logx = cls.c[c].logb - LOGP;
+  const unsigned g = (local >> 3) & ((1u << logx) - 1u);      // which part of the block's residues
+  const unsigned seq = local >> (3 + logx), nr = unsigned(cls.c[c].nrows);
   const unsigned blk = (seq / nr) * 8u + (local & 7u);
   if (blk >= unsigned(cls.c[c].nblocks)) return;
   const RowDesc rd = rows[cls.c[c].row_first + int(seq % nr)];
-  const int H = cls.c[c].halo, L = P - 2 * H;
-  const cplx<T>* xb = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGP>();
+  const int H = cls.c[c].halo, L = (P << logx) - 2 * H;
+  const cplx<T>* xb = xs + cls.c[c].xs_off + long(blk) * ((P << logx) / 2 + 8);
   const long col0 = long(blk) * L;
   const long left = ncols - col0;
   const int nlim = left < L ? int(left) : L;
   cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
 #define CWT_OLS_CASE(LK)                                                                            \
   case LK:                                                                                           \
-    if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP>(xb, rd, mo, tw_all, twn, logN, wout, H, nlim, lds); \
-    else ols_full_body<T, LOGP>(xb, rd, mo, tw_all, wout, H, nlim, lds);                            \
+    if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP, MK>(xb, rd, mo, tw_all, twn, logN, wout, H, nlim, lds, logx, g); \
+    else ols_full_body<T, LOGP, MK>(xb, rd, mo, tw_all, wout, H, nlim, lds);                        \
     break;
   switch (rd.logK) {
     CWT_OLS_CASE(4) CWT_OLS_CASE(5) CWT_OLS_CASE(6) CWT_OLS_CASE(7) CWT_OLS_CASE(8) CWT_OLS_CASE(9)
     CWT_OLS_CASE(10) CWT_OLS_CASE(11) CWT_OLS_CASE(12) CWT_OLS_CASE(13)
-    default: ols_full_body<T, LOGP>(xb, rd, mo, tw_all, wout, H, nlim, lds); break;
+    default: ols_full_body<T, LOGP, MK>(xb, rd, mo, tw_all, wout, H, nlim, lds); break;
   }
 #undef CWT_OLS_CASE
 }

@@ -281,13 +281,18 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, int LOGL, int LOGTB, bool PLANES>
+// PADDED (PLANES only, TB <= 8, TB*L >= 256): the planes layout with one pad element per 16, a + (a >> 4), a = pos*TB + t.
+// Without it the stage-0 writes of a workgroup with few FFTs (lanes 16*TB elements apart) all fall on the same banks
+// (32-way conflict at TB = 2, 16-way at TB = 4); with it lane pairs are 17*TB apart.  Offsets stay immediates: every
+// stride is a multiple of 16 elements except the stage-0 slot stride TB, whose pad (n*TB) >> 4 does not depend on t.
+template <typename T, int LOGL, int LOGTB, bool PLANES, bool PADDED = false>
 struct Fft {
   static constexpr int L = 1 << LOGL, TB = 1 << LOGTB, LOGNT = LOGL - 4, NT = 1 << LOGNT;
   static constexpr int NFULL = LOGL / 4, REM = LOGL % 4;
   static constexpr bool WAVE_LOCAL = !PLANES && NT <= 64;   // every FFT lives inside one wavefront
   static_assert(PLANES || LOGL >= 8, "ROWS layout needs L >= 256");
-  static constexpr int LDS_ELEMS = PLANES ? (TB * L) : (TB * L + ((TB * L) >> 4));
+  static_assert(!PADDED || (PLANES && LOGTB <= 3 && LOGL + LOGTB >= 8), "padded planes: TB <= 8, tile >= 256");
+  static constexpr int LDS_ELEMS = (PLANES && !PADDED) ? (TB * L) : (TB * L + ((TB * L) >> 4));
 
   int t, j;   // FFT index in the workgroup, thread index in the FFT
 
@@ -296,19 +301,27 @@ struct Fft {
   }
   // physical element index of position pos (pos may carry any multiple-of-16 part)
   __device__ __forceinline__ int phys(int pos) const {
-    if constexpr (PLANES) return (pos << LOGTB) + t;
+    if constexpr (PADDED) { const int a = (pos << LOGTB) + t; return a + (a >> 4); }
+    else if constexpr (PLANES) return (pos << LOGTB) + t;
     else { const int a = (t << LOGL) + pos; return a + (a >> 4); }
   }
   // physical stride that corresponds to a logical stride (multiple of 16 for ROWS)
-  static constexpr int pstride(int s) { return PLANES ? (s << LOGTB) : (s + (s >> 4)); }
+  static constexpr int pstride(int s) {
+    return PADDED ? ((s << LOGTB) + ((s << LOGTB) >> 4)) : PLANES ? (s << LOGTB) : (s + (s >> 4));
+  }
 
   // one real plane: slot n -> position wbase + n*Ns ; slot e <- position j + e*NT
   template <int LOGNS>
   __device__ __forceinline__ void exchange(T (&v)[16], T* lds, int wphys, int rphys) const {
     constexpr int WS = (LOGNS == 0) ? (PLANES ? TB : 1) : pstride(1 << LOGNS);
     constexpr int RS = (NT >= 16 || PLANES) ? pstride(NT) : 0;
+    if constexpr (PADDED && LOGNS == 0) {      // slot stride TB < 16: wphys = phys(16 j), slot n adds n*TB + its pad
 #pragma unroll
-    for (int n = 0; n < 16; ++n) lds[wphys + n * WS] = v[n];
+      for (int n = 0; n < 16; ++n) lds[wphys + n * TB + ((n * TB) >> 4)] = v[n];
+    } else {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) lds[wphys + n * WS] = v[n];
+    }
     sync();
     if constexpr (NT >= 16 || PLANES) {
 #pragma unroll
