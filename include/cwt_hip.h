@@ -85,8 +85,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
  *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
- *   "ols_big"      0 = no double-length blocks (precision 64: rows with halo >= "ols_big_min_halo", default 1536, and a
- *                  block support <= 1/8 tile use blocks of two workgroup tiles)
+ *   "ols_big"      1 = rows with halo >= "ols_big_min_halo" (default 1536) and a block support <= 1/8 tile use blocks
+ *                  of two workgroup tiles (default: 1 for precision 32, 0 for 64, where it measured no gain)
+ *   "ols_tile"     points per workgroup of the overlap-save rows: 8192 (default) or, precision 32 only, 16384
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)

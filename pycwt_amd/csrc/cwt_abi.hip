@@ -167,7 +167,8 @@ struct cwt_plan {
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
-  int ols_big = 1;         // fp64: blocks of 2P points for rows with long halos (two workgroups per block)
+  int ols_tile = 8192;     // points per workgroup of those rows (fp32: 8192 or 16384)
+  int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
   int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
   double ols_fwd_weight = 1.0;   // cost of one block spectrum in units of one row's block transform (class grouping)
@@ -201,6 +202,7 @@ struct cwt_plan {
     std::vector<Group> narrow_groups;
     int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
     int n_ols = 0, ols_first = 0;        // overlap-save rows (after the wide rows), sorted by halo class
+    int ols_logp = 13;                   // log2 of their workgroup tile
     OlsClasses ols_cls;
     long ols_wgs = 0, ols_xs_elems = 0;
     long ols_fwd_blocks[2] = {0, 0};     // blocks of P points, blocks of 2P points
@@ -225,6 +227,8 @@ struct cwt_plan {
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
   hipEvent_t ev_ols = nullptr;
+  hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
+  hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
@@ -428,12 +432,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const bool big_ok = p->use_ct && p->narrow_big && p->prec == 64 && narrow_cap >= 10 && logP == 13 &&
                       p->logN >= 14;
   // overlap-save rows: default geometry, at least 4 workgroup tiles per row, built-in mothers, one shared spectrum
-  const int ols_logp = p->prec == 64 ? 13 : 14;
-  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == ols_logp && p->logN >= ols_logp + 2 &&
+  // workgroup tile of the overlap-save rows: 8192 points (512 threads); fp32 may also use 16384 (option "ols_tile")
+  const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : 13;
+  p->rt->ols_logp = ols_logp;
+  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && p->logN >= ols_logp + 2 &&
                       mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
-  const bool ols_big = ols_ok && p->ols_big && p->prec == 64 && p->logN >= ols_logp + 3;   // blocks of 2P points
+  const bool ols_big = ols_ok && p->ols_big && ols_logp == 13 && p->logN >= ols_logp + 3;   // blocks of 2P points
   const double ols_ch = ols_ok ? time_halo_factor(mother, param, p->prec == 64 ? 1e-17 : 5e-7) : 0.0;
   // "not clipped at Nyquist": the profile at the Nyquist bins is below this fraction of its peak (the jump there is what
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
@@ -641,6 +647,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       p->rt->ols_fwd_blocks[lb - ols_logp] = blk;
       row0 += nr;
     }
+    for (int i = 0; i < OLS_MAX_CLASSES; ++i) oc.wg_first[i] = i < oc.n ? oc.c[i].wg_first : 0x7fffffff;
     for (auto& r : ols_rows) { r.nterms = 1 << (int(r.tab_off) - ols_logp); r.tab_off = 0; }   // nterms = workgroups per block
     p->rt->ols_wgs = wg; p->rt->ols_xs_elems = xs;
     p->rt->table.insert(p->rt->table.end(), ols_rows.begin(), ols_rows.end());
@@ -990,31 +997,32 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
 }
 
 // Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd) ...
-template <typename T, int LOGB>
+template <typename T, int LOGM, int LOGD>
 int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, hipStream_t st) {
-  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGB>), true);
+  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGM, LOGD>), true);
   (void)once;
-  const size_t lds = ((size_t(1) << LOGB) + (size_t(1) << (LOGB - 4))) * sizeof(T);
+  const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
   return timed_launch(p, KC_OLS_FWD, [&] {
-    hipLaunchKernelGGL((k_ols_fwd<T, LOGB>), dim3(unsigned(blocks)), dim3(1 << (LOGB - 4)), lds, st,
+    hipLaunchKernelGGL((k_ols_fwd<T, LOGM, LOGD>), dim3(unsigned(blocks << LOGD)), dim3(1 << (LOGM - 4)), lds, st,
                        static_cast<const T*>(x_dev), long(n0), p->logN, p->rt->ols_cls,
-                       static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xs));
+                       static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
   }, st);
 }
 template <typename T>
 int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
-  constexpr int LOGP = default_logp<T>();
+  const long* nb = p->rt->ols_fwd_blocks;
   int rc = CWT_OK;
-  if (p->rt->ols_fwd_blocks[0]) rc = launch_ols_fwd_b<T, LOGP>(p, x_dev, n0, p->rt->ols_fwd_blocks[0], st);
-  if constexpr (sizeof(T) == 8) {
-    if (!rc && p->rt->ols_fwd_blocks[1]) rc = launch_ols_fwd_b<T, LOGP + 1>(p, x_dev, n0, p->rt->ols_fwd_blocks[1], st);
+  if (p->rt->ols_logp == 13) {
+    if (nb[0]) rc = launch_ols_fwd_b<T, 13, 0>(p, x_dev, n0, nb[0], st);
+    if (!rc && nb[1]) rc = launch_ols_fwd_b<T, 13, 1>(p, x_dev, n0, nb[1], st);   // double-length blocks, two tiles each
+  } else if constexpr (sizeof(T) == 4) {
+    if (nb[0]) rc = launch_ols_fwd_b<T, 14, 0>(p, x_dev, n0, nb[0], st);
   }
   return rc;
 }
 // ... and the rows themselves (k_ols_ct)
-template <typename T>
-int launch_ols_rows(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
-  constexpr int LOGP = default_logp<T>();
+template <typename T, int LOGP>
+int launch_ols_rows_p(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
   static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_MORLET>), allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_PAUL>),
                             allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_DOG>), true);
@@ -1032,6 +1040,13 @@ int launch_ols_rows(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int6
     else CWT_OLS_LAUNCH(MOTHER_DOG);
 #undef CWT_OLS_LAUNCH
   }, st);
+}
+template <typename T>
+int launch_ols_rows(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (p->rt->ols_logp == 14) return launch_ols_rows_p<T, 14>(p, mo, W, ldw, ncols, st);
+  }
+  return launch_ols_rows_p<T, 13>(p, mo, W, ldw, ncols, st);
 }
 
 template <typename T>
@@ -1150,10 +1165,21 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       narrow_class_counts(p, &n_small_k, &n_big, &n_many);
       rc = CWT_OK;
       if (n_small_k) rc = timed_launch(p, KC_NARROW, [&] { launch_narrow_ct_all<T>(p, xhat, mo, W, ldw, ncols); });
+      // the multi-term kernels (few rows, long workgroups) on a stream of their own: at small row counts (a rank's
+      // share of 8) they would otherwise run alone at the end of the step
+      const bool big_on_side2 = narrow_on_side && n_small_k && (n_many || n_big);
+      if (big_on_side2) {
+        HIPCHECK(hipStreamWaitEvent(p->side2, p->ev_fork, 0));
+        p->stream = p->side2;
+      }
       if (!rc && n_many) rc = timed_launch(p, KC_NARROW_MANY, [&] { launch_narrow_ct_many<T>(p, xhat, mo, W, ldw, ncols); });
       if (!rc && n_big) rc = timed_launch(p, KC_NARROW_BIG, [&] { launch_narrow_ct_big<T>(p, xhat, mo, W, ldw, ncols); });
       p->stream = keep;
       if (rc) return rc;
+      if (big_on_side2) {
+        HIPCHECK(hipEventRecord(p->ev_big, p->side2));
+        HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_big, 0));          // joined through side stream 0
+      }
       if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
     } else {
       for (const auto& g : p->rt->narrow_groups) {
@@ -1312,6 +1338,9 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
+    rc = fail(CWT_EHIP, "cannot create side streams/events");
+  p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
     if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "row table allocation failed");
@@ -1342,6 +1371,8 @@ int cwt_plan_destroy(cwt_plan* p) {
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
+  if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
+  if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
@@ -1413,6 +1444,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols") p->ols = value != 0;
   else if (k == "ols_side") p->ols_side = value != 0;
   else if (k == "ols_big") p->ols_big = value != 0;
+  else if (k == "ols_tile") { if (value != 8192 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }

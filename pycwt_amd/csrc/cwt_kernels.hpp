@@ -950,6 +950,7 @@ struct OlsClass {
 constexpr int OLS_MAX_CLASSES = 16;
 struct OlsClasses {
   OlsClass c[OLS_MAX_CLASSES];
+  int wg_first[OLS_MAX_CLASSES];   // copy of c[i].wg_first (INT_MAX beyond n): one scalar load finds a workgroup's class
   int n;
 };
 template <int LOGP> constexpr int ols_stride() { return (1 << (LOGP - 1)) + 8; }   // complex elements per block spectrum
@@ -985,36 +986,69 @@ __device__ __forceinline__ cplx<T> ols_apply(cplx<T> x, const RowDesc& rd, const
   return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
 }
 
-// Half spectra of the input blocks of the classes with block length 2^LOGB: one workgroup = one block.
-template <typename T, int LOGB>
-__global__ void __launch_bounds__(1 << (LOGB - 4), (LOGB - 4 >= 10 ? 4 : 4))
-k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all,
+// Half spectra of the input blocks of the classes with block length P_b = 2^(LOGM + LOGD) on M = 2^LOGM-point
+// workgroup tiles.  LOGD = 0: one workgroup = one block.  LOGD = 1: the first radix-2 step of a decimation-in-frequency
+// transform is done while loading -- workgroup (block, c) computes the bins 2k + c as the M-point transform of
+// x0 + x1 (c = 0: real input again) or (x0 - x1) e^{-2 pi i n / P_b} (c = 1), x0 / x1 = the two halves of the block --
+// so that double-length blocks run on the same 8192-point tiles as everything else (a 16384-point workgroup holds one
+// tile per CU and measured 80 us for 340 blocks).  Only bins <= P_b / 2 are kept (x is real).
+template <typename T, int LOGM, int LOGD>
+__global__ void __launch_bounds__(1 << (LOGM - 4), 4)
+k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all, TwN<T> twn,
           cplx<T>* __restrict__ xs) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
-  constexpr int P = 1 << LOGB, NT = P >> 4;
-  using F = ct::Fft<T, LOGB, 0, false>;
+  constexpr int M = 1 << LOGM, NT = M >> 4, LOGB = LOGM + LOGD, PB = 1 << LOGB;
+  using F = ct::Fft<T, LOGM, 0, false>;
+  const int wg = int(blockIdx.x) >> LOGD, part = int(blockIdx.x) & ((1 << LOGD) - 1);
   int c = 0;
   for (int i = 0; i < cls.n; ++i)
-    if (cls.c[i].logb == LOGB && int(blockIdx.x) >= cls.c[i].blk_first) c = i;
-  const int blk = int(blockIdx.x) - cls.c[c].blk_first, H = cls.c[c].halo, L = P - 2 * H;
+    if (cls.c[i].logb == LOGB && wg >= cls.c[i].blk_first) c = i;
+  const int blk = wg - cls.c[c].blk_first, H = cls.c[c].halo, L = PB - 2 * H;
   const long nmask = (1L << logN) - 1;
   const long first = long(blk) * L - H;
   F f;
   f.t = 0;
   f.j = threadIdx.x;
   T re[16], im[16];
+  if constexpr (LOGD == 0) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const long n = (first + f.j + e * NT) & nmask;
-    re[e] = n < n0 ? x[n] : T(0);
-    im[e] = T(0);
+    for (int e = 0; e < 16; ++e) {
+      const long n = (first + f.j + e * NT) & nmask;
+      re[e] = n < n0 ? x[n] : T(0);
+      im[e] = T(0);
+    }
+  } else {
+    static_assert(LOGD == 1, "one radix-2 step");
+    T a[16], b[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long na = (first + f.j + e * NT) & nmask, nb = (first + M + f.j + e * NT) & nmask;
+      a[e] = na < n0 ? x[na] : T(0);
+      b[e] = nb < n0 ? x[nb] : T(0);
+    }
+    if (part == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { re[e] = a[e] + b[e]; im[e] = T(0); }
+    } else {
+      // the engine runs the inverse direction: conj(input) = (x0 - x1) e^{+2 pi i n / P_b}, n = j + e NT
+      const int sh = logN - LOGB;
+      cplx<T> cur = twn(unsigned(f.j) << sh);
+      const cplx<T> step = twn(unsigned(NT) << sh);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const T d = a[e] - b[e];
+        re[e] = d * cur.x; im[e] = d * cur.y;
+        if (e < 15) cur = cmul<T>(cur, step);
+      }
+    }
   }
-  f.run(re, im, lds, tw_all + (P - 2));
-  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ols_stride<LOGB>();
+  f.run(re, im, lds, tw_all + (M - 2));
+  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ((PB >> 1) + 8);
+  // bin (k << LOGD) + part, k = j + e NT, kept while <= P_b / 2: forward = conj(inverse(conj input))
 #pragma unroll
-  for (int e = 0; e < 8; ++e) out[f.j + e * NT] = mk<T>(re[e], -im[e]);      // forward = conj(inverse) for real input
-  if (f.j == 0) out[P / 2] = mk<T>(re[8], -im[8]);
+  for (int e = 0; e < 8; ++e) out[((f.j + e * NT) << LOGD) + part] = mk<T>(re[e], -im[e]);
+  if (f.j == 0 && part == 0) out[PB / 2] = mk<T>(re[8], -im[8]);
 }
 
 // Block transform with K = P: every thread filters its own 16 bins (rows whose block support exceeds P/2 bins).
@@ -1118,8 +1152,9 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mothe
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int P = 1 << LOGP;
-  int c = 0;
-  while (c + 1 < cls.n && int(blockIdx.x) >= cls.c[c + 1].wg_first) ++c;
+  int c = -1;
+#pragma unroll
+  for (int i = 0; i < OLS_MAX_CLASSES; ++i) c += int(blockIdx.x) >= cls.wg_first[i];   // independent compares, no loop-carried loads
   const unsigned local = blockIdx.x - unsigned(cls.c[c].wg_first);
   const int logx = cls.c[c].logb - LOGP;
   const unsigned g = (local >> 3) & ((1u << logx) - 1u);      // which part of the block's residues

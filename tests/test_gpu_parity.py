@@ -557,3 +557,67 @@ def test_unpadded_transform_lengths_on_gpu(hip_library, precision, tol):
         ref = orc.cwt(x.astype(np.float32) if precision == 32 else x, 1.0, dj, -1, -1, "morlet", pad=False)
         per_row, _ = row_errors(out[0], ref[0])
         assert out[0].shape == ref[0].shape and per_row.max() < tol, (n0, per_row.max())
+
+
+@pytest.mark.parametrize("name,prec,logn,n0_off", [("morlet", 64, 18, 0), ("morlet", 64, 20, 12345), ("morlet", 32, 19, 7),
+                                                   ("paul", 32, 20, 1), ("paul", 64, 17, 0), ("dog", 32, 20, 0),
+                                                   ("dog", 64, 19, 4097)])
+def test_overlap_save_rows_on_gpu(hip_library, name, prec, logn, n0_off):
+    """cwt_transform (the signal is known: time-compact rows go block by block through k_ols_fwd / k_ols_ct, incl. the
+    double-length blocks) against cwt_forward_fft + cwt_transform_rows (the same rows through the two-pass / band-limited
+    kernels) on every row, against the oracle on a row sample, and bit for bit across the stream options."""
+    N = 1 << logn
+    n0 = N - n0_off
+    kind, param = MOTHERS[name]
+    m = orc.Mother(kind, param)
+    sj = grid(n0, 1.0, m, 96)
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    x = np.random.default_rng(logn + n0_off).standard_normal(n0).astype(real)
+    plan = _hip.Plan(N, prec, max_rows=len(sj), options={"ols_big": 1})     # default: fp32 only
+    xd, xh = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 2 * x.itemsize)
+    Wa, Wb = (_hip.DeviceBuffer(len(sj) * n0 * 2 * x.itemsize) for _ in range(2))
+    xd.upload(plan, x)
+    plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wa.ptr, n0, n0)
+    split, classes = plan.last_split(), plan.row_classes()
+    if name == "paul" and prec == 64:      # polynomial tails: no halo reaches 1e-17 of the wavelet's mass -> never taken
+        assert split["ols"] == 0
+        for b in (xd, xh, Wa, Wb):
+            b.free()
+        plan.close()
+        return
+    assert split["ols"] >= 8, split
+    if logn >= 18 and name != "paul":
+        assert any(c.startswith("ols2/") for c in classes), sorted(set(classes))
+    A = Wa.download(plan, (len(sj), n0), cplx)
+    plan.forward_fft(xd.ptr, n0, xh.ptr)
+    plan.transform_rows(xh.ptr, kind, param, 1.0, sj, Wb.ptr, n0, n0)
+    assert plan.last_split()["ols"] == 0
+    B = Wb.download(plan, (len(sj), n0), cplx)
+    per_row, _ = row_errors(A, B)
+    assert per_row.max() < TOL[prec], (per_row.argmax(), classes[per_row.argmax()], per_row.max())
+    mine = [i for i, c in enumerate(classes) if c.startswith("ols")]
+    pick = mine[::max(1, len(mine) // 6)]
+    with np.errstate(all="ignore"):
+        ref = orc.cwt_rows(x, 1.0, sj[pick], m, N=N)[:, :n0]
+    per_row, _ = row_errors(A[pick], ref)
+    assert per_row.max() < TOL[prec], (per_row, [classes[i] for i in pick])
+    for opts in ({"ols_early": 0}, {"ols_early": 0, "ols_side": 0}, {"overlap_narrow": 0}):
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
+        assert np.array_equal(Wb.download(plan, (len(sj), n0), cplx), A), opts
+        for k in opts:
+            plan.set_option(k, 1)
+    plan.set_option("ols_big", 0)
+    plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
+    per_row, _ = row_errors(Wb.download(plan, (len(sj), n0), cplx), A)
+    assert per_row.max() < TOL[prec]
+    if prec == 32:
+        plan.set_option("ols_tile", 16384)
+        plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
+        assert plan.last_split()["ols"] >= 8
+        per_row, _ = row_errors(Wb.download(plan, (len(sj), n0), cplx), A)
+        assert per_row.max() < TOL[prec]
+    for b in (xd, xh, Wa, Wb):
+        b.free()
+    plan.close()

@@ -350,3 +350,25 @@ def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
     for b in (xd, xh, Wd):
         b.free()
     plan.close()
+
+
+@pytest.mark.parametrize("kind,param,prec,opts", [
+    (orc.MORLET, 6, 64, {"ols_big": 1, "ols_big_min_halo": 256}),   # fp64: double-length blocks are opt-in
+    (orc.MORLET, 6, 64, {"ols_big": 0}),
+    (orc.DOG, 2, 32, {"ols_tile": 16384}),                 # fp32 on 16384-point tiles (no double-length blocks)
+    (orc.PAUL, 4, 32, {"ols_big_min_halo": 512}),
+])
+def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opts):
+    N = 1 << 17
+    x = np.random.default_rng(8).standard_normal(N - 77)
+    m = orc.Mother(kind, param)
+    sj = grid(x.size, 1.0, m, 72)
+    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=opts)
+    W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+    split, classes = plan.last_split(), plan.row_classes()
+    plan.close()
+    assert split["ols"] >= 6, split
+    big = [c for c in classes if c.startswith("ols2/")]
+    assert bool(big) == (opts.get("ols_big", int(prec == 32)) == 1 and opts.get("ols_tile", 8192) == 8192), sorted(set(classes))
+    per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
+    assert per_row.max() < TOL[prec], (per_row.argmax(), classes[per_row.argmax()], per_row.max())

@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage: tools/gpu_profile.sh <tag> [bench args]  -- rocprofv3 kernel stats + PMC passes of bench.py
 # trace      : the default command (band-limited rows overlap the two-pass chain on a side stream in the timed loop)
-# trace_ser  : the same with --opt overlap_narrow=0 (every kernel alone: durations comparable with bench.py's HIP events)
+# trace_ser  : the same with --opt overlap_narrow=0 --opt ols_early=0 --opt ols_side=0 (every kernel alone: durations comparable with bench.py's HIP events)
 # pmc_*      : counter passes (kernel trace only, one counter group per pass), serialized kernels
 export TMPDIR=/tmp
 tag=$1; shift
 OUT=$PWD/gpurun_out/$tag
 mkdir -p $OUT
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
-SER="$BENCH --opt overlap_narrow=0"
+SER="$BENCH --opt overlap_narrow=0 --opt ols_early=0 --opt ols_side=0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o cwt -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ser -o cwt -- $SER > $OUT/trace_ser.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o cwt -- $SER > $OUT/pmc_sq1.log 2>&1

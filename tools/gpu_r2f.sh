@@ -1,0 +1,6 @@
+#!/bin/bash
+export TMPDIR=/tmp
+OUT=gpurun_out/r2f
+mkdir -p $OUT
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_gpu.log
