@@ -8,7 +8,8 @@ FFT -> all rows of W written device-resident.  Inputs are resident in HBM when t
 
 Workload at 1 GPU = BASELINE.json configs[1]: N = 2^20 fp64 samples, Morlet(6), 256 scales spanning
 s0 = 2dt/flambda .. N*dt.  With G GPUs (one process per GPU, launched by torch.distributed.run) the
-SAME 256 rows are split over the ranks, row j -> rank j mod G (STRONG scaling, the quantity north_star's ">= 6x at
+SAME 256 rows are split over the ranks -- contiguous runs of scales of equal estimated cost (`--partition balanced`,
+default) or row j -> rank j mod G (`--partition interleaved`) -- (STRONG scaling, the quantity north_star's ">= 6x at
 8 GPUs" is about); rank 0 owns the signal and broadcasts it over RCCL each step, the broadcast of step i+1
 travelling while step i computes; there is no other collective.  `--weak` (and the `weak_scaling` block of the
 default multi-GPU line) refines the grid to 256*G rows instead, 256 per GPU.
@@ -134,14 +135,24 @@ class Workload:
     """One BASELINE configuration on this rank: the signal, this rank's rows (j = rank mod world) of a
     `rows_total`-row scale grid, the device buffers and the plan."""
 
-    def __init__(self, rt, config, logn, rows_total, opts):
+    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced"):
         from pycwt_amd import _hip
         torch = rt.torch
         self.rt, self.config = rt, config
         self.kind, self.param, self.prec, self.label = CONFIGS[config]
         self.N, self.dt, self.rows_total = 1 << logn, 1.0, rows_total
         self.sj_all = scale_grid(self.N, self.dt, flambda_of(self.kind, self.param), rows_total)
-        self.mine = np.arange(rt.shard[0], rows_total, rt.shard[1])
+        self.opts = dict(opts)
+        self.plan = _hip.Plan(self.N, self.prec, max_rows=rows_total, device=rt.device_index, lib=rt.lib,
+                              options=self.opts)
+        if rt.shard[1] > 1 and partition == "balanced":
+            # contiguous shards of equal estimated cost (pycwt_amd.parallel.balanced_shards): every rank classifies the
+            # whole grid -- host arithmetic, identical on all ranks -- and takes its run of scales
+            from pycwt_amd.parallel import balanced_shards
+            labels = self.plan.classify(self.kind, self.param, self.dt, self.sj_all, self.N, True)
+            self.mine = balanced_shards(labels, rt.shard[1], self.prec)[rt.shard[0]]
+        else:
+            self.mine = np.arange(rt.shard[0], rows_total, rt.shard[1])
         self.sj = np.ascontiguousarray(self.sj_all[self.mine])
         real_t = torch.float64 if self.prec == 64 else torch.float32
         cplx_t = torch.complex128 if self.prec == 64 else torch.complex64
@@ -156,17 +167,14 @@ class Workload:
         self.xbuf = [x, x.clone()]
         self.xhat = torch.empty(self.N, dtype=cplx_t, device=rt.dev)
         self.W = torch.empty((max(len(self.sj), 1), self.N), dtype=cplx_t, device=rt.dev)
-        self.opts = dict(opts)
-        self.plan = _hip.Plan(self.N, self.prec, max_rows=max(len(self.sj), 1), device=rt.device_index, lib=rt.lib,
-                              options=self.opts)
         self.plan.set_stream(rt.stream_handle())
+        self.sharded = rt.shard[1] > 1
 
     def compute(self, buf):
-        if len(self.sj):   # forward FFT + every row of W in one call (wavelet.py:91-106)
-            self.plan.transform(buf.data_ptr(), self.N, self.kind, self.param, self.dt, self.sj, self.xhat.data_ptr(),
-                                self.W.data_ptr(), self.N, self.N)
-        else:
-            self.plan.forward_fft(buf.data_ptr(), self.N, self.xhat.data_ptr())
+        if len(self.sj):   # forward FFT + every row of W in one call (wavelet.py:91-106); a rank of a sharded transform
+            # has no use for the spectrum itself (None: kept in plan scratch, skipped if none of its rows needs it)
+            self.plan.transform(buf.data_ptr(), self.N, self.kind, self.param, self.dt, self.sj,
+                                None if self.sharded else self.xhat.data_ptr(), self.W.data_ptr(), self.N, self.N)
 
     def run_steps(self, count):
         """`count` steps.  With more than one rank the broadcast of step i+1 is issued (async, on RCCL's own
@@ -342,7 +350,7 @@ class Workload:
 
 
 def measure(rt, config, args, rows_total, opts, want_cpu):
-    wl = Workload(rt, config, args.logn, rows_total, opts)
+    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition)
     out = wl.timed(args.steps, args.warmup)
     out["roofline"] = wl.roofline(args.steps)
     if want_cpu:
@@ -364,6 +372,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--rows", type=int, default=256, help="rows of the scale grid (per GPU with --weak)")
+    ap.add_argument("--partition", default="balanced", choices=["balanced", "interleaved"],
+                    help="rows of a rank with more than one GPU: contiguous scales of equal estimated cost (default) or j = rank mod G")
     ap.add_argument("--weak", action="store_true", help="weak scaling: --rows rows per GPU of a rows*G-row grid")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline / parity / extra")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 block of the default run")
@@ -395,7 +405,8 @@ def main():
     head = measure(rt, args.config, args, rows_total, opts, want_cpu=single and rank == 0)
     workload = f"N=2^{args.logn} {label} {rows_total} scales"
     if world > 1:
-        workload += f" split over {world} GPUs (row j -> rank j mod {world})"
+        workload += (f" split over {world} GPUs (contiguous cost-balanced shards)" if args.partition == "balanced"
+                     else f" split over {world} GPUs (row j -> rank j mod {world})")
     out = {
         "metric": "CWT GSamples*scales/s at N=2^20, J=256", "value": head["value"], "unit": "GSamples*scales/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],

@@ -131,6 +131,8 @@ int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double 
  * psi_ft sampled on the block's coarser frequency grid -- no N-point inverse transform, no intermediate in memory,
  * contiguous stores.  The neglected tail of the wavelet is below 1e-17 (precision 64) / 5e-7 (32) of its L1 mass.
  * x_dev: n0 reals.  Option "ols" = 0 turns that form off (then exactly the two calls above).                       */
+/* xhat_dev may be NULL when the caller has no use for the spectrum: it is then computed into plan scratch, and not at
+ * all when every row takes the overlap-save form (a rank of a scale-sharded transform that owns only such rows). */
 int cwt_transform(cwt_plan* plan, const void* x_dev, int64_t n0, int mother, double param, double dt,
                   const double* scales_host, int nrows, void* xhat_dev, void* W_dev, int64_t ldw,
                   int64_t ncols);
@@ -253,6 +255,11 @@ int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_
  * *n = number of rows of the call; codes may be NULL.  The parity
  * tests and bench.py use it to report the worst row per kernel class.                                          */
 int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
+/* The same codes for a transform that has not run yet: classifies `nrows` scales exactly as cwt_transform
+ * (with_signal = 1) or cwt_transform_rows (0) with these arguments would, without launching anything.
+ * pycwt_amd.parallel uses it to cut a scale grid into cost-balanced contiguous shards.                        */
+int cwt_plan_classify(cwt_plan* plan, int mother, double param, double dt, const double* scales_host, int nrows,
+                      int64_t ncols, int with_signal, int* codes);
 /* Diagnostics: with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
  * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
  * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in

@@ -63,6 +63,8 @@ SYMBOLS = [
     ("cwt_plan_timings", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("cwt_plan_row_classes", C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    ("cwt_plan_classify", C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int64,
+                                    C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
 ]
@@ -188,12 +190,13 @@ class Plan:
                                                    _dptr(s), s.size, _P(W_dev), ldw, ncols))
 
     @_locked
-    def transform(self, x_dev: int, n0: int, mother: int, param: float, dt: float, scales, xhat_dev: int, W_dev: int,
+    def transform(self, x_dev: int, n0: int, mother: int, param: float, dt: float, scales, xhat_dev, W_dev: int,
                   ldw: int, ncols: int):
-        """forward_fft + transform_rows in one call; the library may use the signal itself (overlap-save rows)."""
+        """forward_fft + transform_rows in one call; the library may use the signal itself (overlap-save rows).
+        xhat_dev = None: the spectrum is not wanted (computed into plan scratch only if some row needs it)."""
         s = np.ascontiguousarray(scales, dtype=np.float64)
         self.lib.check(self.lib.cwt_transform(self.h, _P(x_dev), n0, mother, float(param), float(dt), _dptr(s), s.size,
-                                              _P(xhat_dev), _P(W_dev), ldw, ncols))
+                                              _P(xhat_dev) if xhat_dev else None, _P(W_dev), ldw, ncols))
 
     @_locked
     def forward_fft_n(self, x_dev: int, n0: int, xhat_dev: int):
@@ -307,13 +310,27 @@ class Plan:
     @_locked
     def row_classes(self):
         """Kernel class of every row of the last transform call, as labels like 'narrow/K1024/t3',
-        'narrow_k2048/t4', 'two_pass/full', 'two_pass/c64' (see cwt_plan_row_classes)."""
+        'narrow_k2048/t4', 'two_pass/full', 'two_pass/c64', 'ols/K512' (see cwt_plan_row_classes)."""
         n = C.c_int(0)
         self.lib.check(self.lib.cwt_plan_row_classes(self.h, None, 0, C.byref(n)))
         codes = (C.c_int * max(n.value, 1))()
         self.lib.check(self.lib.cwt_plan_row_classes(self.h, codes, n.value, C.byref(n)))
+        return self._labels(codes[:n.value])
+
+    @_locked
+    def classify(self, mother: int, param: float, dt: float, scales, ncols: int, with_signal: bool = True):
+        """The labels `row_classes()` would report after transform() (with_signal) / transform_rows() with these
+        arguments; nothing is launched."""
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        codes = (C.c_int * max(s.size, 1))()
+        self.lib.check(self.lib.cwt_plan_classify(self.h, mother, float(param), float(dt), _dptr(s), s.size, ncols,
+                                                  int(with_signal), codes))
+        return self._labels(codes[:s.size])
+
+    @staticmethod
+    def _labels(codes):
         out = []
-        for c in codes[:n.value]:
+        for c in codes:
             kind, logk, terms = c // 10000, (c // 100) % 100, c % 100
             if kind == 0:
                 out.append("single_wg")

@@ -1608,11 +1608,21 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
 
 int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double param, double dt,
                   const double* scales, int nrows, void* xhat_dev, void* W_dev, int64_t ldw, int64_t ncols) {
-  if (!p || !x_dev || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (!p || !x_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
+  if (!xhat_dev) {   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
+    if (p->rt->n_ols == int(p->rt->table.size())) {
+      const Mother mo = mother_of(mother, param);
+      return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
+                           : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+    }
+    rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * 2 * p->esize(), p->stream);
+    if (rc) return rc;
+    xhat_dev = p->hxhat;
+  }
   const Mother mo = mother_of(mother, param);
   p->ols_launched = 0;
   if (p->rt->n_ols && p->ols_early && !p->profile && !p->overlap) {
@@ -2094,6 +2104,16 @@ int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
     if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
   }
   return CWT_OK;
+}
+
+int cwt_plan_classify(cwt_plan* p, int mother, double param, double dt, const double* scales, int nrows, int64_t ncols,
+                      int with_signal, int* codes) {
+  if (!p || !scales || !codes) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(p->device));
+  int rc = prepare_rows_table(p, with_signal != 0, mother, param, dt, scales, nrows, ncols, ncols);
+  if (rc) return rc;
+  int n = 0;
+  return cwt_plan_row_classes(p, codes, nrows, &n);
 }
 
 int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, int64_t* n_records) {

@@ -4,9 +4,9 @@ The rows (scales) of W are independent once the signal is known (pycwt/wavelet.p
 outer product followed by independent inverse FFTs), so the only exchange of the path is ONE
 broadcast per transform: rank 0 owns the signal and broadcasts it (8 MiB at N = 2^20 fp64; backend
 "nccl" = RCCL over xGMI); every rank then runs the forward FFT itself (1/rows of its work, cheaper
-than moving the 16 MiB spectrum) and computes rows j = rank, rank + G, rank + 2G, ... into a
-device-resident shard.  Interleaving balances the load because small scales (two-pass rows) cost
-more than large ones.  W is never gathered (4 GiB would dwarf the compute); `icwt_sharded` reduces
+than moving the 16 MiB spectrum) and computes its rows into a device-resident shard.  The default shards are
+contiguous runs of scales of equal ESTIMATED COST (`balanced_shards`: the library classifies every row first,
+`Plan.classify`); `partition="interleaved"` gives rows j = rank, rank + G, ... instead.  W is never gathered (4 GiB would dwarf the compute); `icwt_sharded` reduces
 per-rank partial column sums with one `reduce`.
 
 torch is plumbing here: device memory, the current stream and the process group.  The compute goes
@@ -24,6 +24,80 @@ from .wavelet import _check_parameter_wavelet, _coi, _device_id, _nan_rows, _nex
 def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
     """Indices of the rows owned by `rank` (interleaved)."""
     return np.arange(rank, nrows, world)
+
+
+# Cost model of one rank's step, microseconds at N = 2^20 (everything scales with N): a fixed part per kernel class
+# that has at least one row (launch ramp and tail, the forward FFT, the block spectra) plus a per-row part.  Fitted
+# to the measured launch durations of bench.py at 1/8 .. 8/8 of BASELINE config 2 / 3 (DESIGN.md section 6).
+_COST = {
+    64: {"fwd": 27.0, "two_pass": (30.0, 7.0), "narrow_k2048": (20.0, 5.4), "ols": (33.0, 4.0), "narrow": (4.0, 2.8),
+         "narrow_t": 1.0},
+    32: {"fwd": 27.0, "two_pass": (25.0, 4.6), "narrow_k2048": (20.0, 5.4), "ols": (30.0, 2.5), "narrow": (4.0, 1.7),
+         "narrow_t": 0.5},
+}
+
+
+def _shard_cost(labels, precision):
+    """Estimated step time of a rank that owns the rows with these class labels."""
+    c = _COST[precision]
+    total, seen = 0.0, set()
+    n_two_pass = sum(1 for lab in labels if lab.startswith("two_pass"))
+    if n_two_pass > 12:                   # one launch pair per chunk of <= 12 rows (the intermediate must fit the cache)
+        total += c["two_pass"][0] * ((n_two_pass - 1) // 12)
+    for lab in labels:
+        kind = lab.split("/")[0]
+        if kind.startswith("ols"):
+            kind = "ols"
+        elif kind == "single_wg":
+            kind = "narrow"
+        fixed, per = c[kind]
+        if kind not in seen:
+            seen.add(kind)
+            total += fixed
+        total += per
+        if kind == "narrow" and "/t" in lab:
+            total += c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
+    if seen - {"ols"}:
+        total += c["fwd"]                 # some row needs the spectrum
+    return total
+
+
+def balanced_shards(labels, world: int, precision: int = 64):
+    """Cuts the scale grid (rows in scale order, `labels` = their kernel classes from `Plan.classify`) into `world`
+    CONTIGUOUS shards of equal estimated cost.  Against interleaving (row j -> rank j mod G) a rank then runs few
+    kernel classes with many rows each instead of every class with a handful -- at 8 ranks the interleaved share
+    is 2-3 two-pass rows, 2 K = 2048 rows, 9 overlap-save rows ..., all launch-latency bound -- and ranks whose rows
+    are all overlap-save never need the forward FFT.  Returns a list of index arrays (possibly empty)."""
+    n = len(labels)
+    if world <= 1 or n == 0:
+        return [np.arange(n)] + [np.arange(0)] * (world - 1)
+
+    def cuts_for(limit):
+        cuts, lo = [], 0
+        for _ in range(world):
+            hi = lo
+            # largest hi with cost(lo:hi) <= limit (cost is monotone in hi)
+            a, b = lo, n
+            while a < b:
+                m = (a + b + 1) // 2
+                if _shard_cost(labels[lo:m], precision) <= limit:
+                    a = m
+                else:
+                    b = m - 1
+            hi = max(a, lo + 1) if lo < n else lo
+            cuts.append((lo, min(hi, n)))
+            lo = min(hi, n)
+        return cuts if lo >= n else None
+
+    lo_t, hi_t = 0.0, _shard_cost(labels, precision)
+    for _ in range(40):
+        mid = 0.5 * (lo_t + hi_t)
+        if cuts_for(mid) is None:
+            lo_t = mid
+        else:
+            hi_t = mid
+    cuts = cuts_for(hi_t)
+    return [np.arange(a, b) for a, b in cuts]
 
 
 class HipEngine:
@@ -53,19 +127,23 @@ class HipEngine:
 
     def transform(self, x, n0, xhat, kind, param, dt, sj, W, ncols):
         """forward + rows; for one signal in ONE C call (cwt_transform), which lets the library use the signal itself
-        for time-compact rows (overlap-save)."""
+        for time-compact rows (overlap-save).  xhat = None: spectrum not wanted (plan scratch, skipped if unused)."""
         if x.dim() == 1:
-            self.plan.transform(x.data_ptr(), n0, kind, param, dt, sj, xhat.data_ptr(), W.data_ptr(), W.shape[-1], ncols)
+            self.plan.transform(x.data_ptr(), n0, kind, param, dt, sj, None if xhat is None else xhat.data_ptr(),
+                                W.data_ptr(), W.shape[-1], ncols)
         else:
             self.forward(x, n0, xhat)
             self.rows(xhat, kind, param, dt, sj, W, ncols)
+
+    def classify(self, kind, param, dt, sj, ncols):
+        return self.plan.classify(kind, param, dt, sj, ncols, True)
 
     def icwt_partial(self, W, sj, out):
         self.plan.icwt_reduce(W.data_ptr(), W.shape[1], W.shape[1], sj, 1.0, out.data_ptr())
 
 
 def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, group=None,
-                precision=64, device=None, engine=None, src=0):
+                precision=64, device=None, engine=None, src=0, partition="balanced"):
     """Scale-sharded `cwt`.  Call on every rank of `group`; only rank `src` needs `signal`.
 
     `signal` may be 2-D (batch x n0): then every rank transforms all signals for its scales and
@@ -106,16 +184,21 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
         sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
     coi = _coi(mother, n0, dt)
 
-    mine = shard_rows(sj.size, world, rank)
     kind, param = _device_id(mother)
     nbatch = shape[0] if len(shape) == 2 else 1
     if engine is None:
-        engine = HipEngine(N, precision, max(1, mine.size * nbatch), device.index or 0, device.type == "cuda")
-    xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
-    W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
-    if mine.size and hasattr(engine, "transform"):
-        engine.transform(x, n0, xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+        cap = sj.size if (partition == "balanced" and nbatch == 1) else -(-sj.size // world) * nbatch
+        engine = HipEngine(N, precision, max(1, cap), device.index or 0, device.type == "cuda")
+    if partition == "balanced" and nbatch == 1 and world > 1 and hasattr(engine, "classify"):
+        mine = balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision)[rank]
     else:
+        mine = shard_rows(sj.size, world, rank)
+    W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
+    if hasattr(engine, "transform") and nbatch == 1:
+        if mine.size:                                     # the spectrum stays inside the library
+            engine.transform(x, n0, None, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+    else:
+        xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
         engine.forward(x, n0, xhat)
         if mine.size:
             engine.rows(xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)

@@ -183,3 +183,29 @@ def test_shard_rows_partition():
             parts = [shard_rows(n, world, r) for r in range(world)]
             assert sorted(np.concatenate(parts)) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_balanced_shards_cover_the_grid_and_even_out_the_cost(emu_library):
+    """Contiguous cost-balanced shards (parallel.balanced_shards on Plan.classify labels): every row exactly once, in
+    scale order, estimated per-rank cost within a few rows of each other, and never worse than interleaving by the
+    same cost model."""
+    from oracle import cwt_oracle as orc
+    from pycwt_amd import _hip, parallel
+    N = 1 << 16
+    m = orc.Mother(orc.MORLET, 6)
+    s0 = 2 / m.flambda()
+    sj = s0 * 2 ** (np.arange(96) * np.log2(N / s0) / 95)
+    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library)
+    labels = plan.classify(orc.MORLET, 6.0, 1.0, sj, N, True)
+    assert len(labels) == len(sj) and any(l.startswith("ols") for l in labels)
+    assert not any(l.startswith("ols") for l in plan.classify(orc.MORLET, 6.0, 1.0, sj, N, False))
+    plan.close()
+    for world in (1, 2, 3, 4, 8):
+        shards = parallel.balanced_shards(labels, world, 64)
+        assert len(shards) == world
+        assert np.array_equal(np.concatenate(shards), np.arange(len(sj)))
+        cost = [parallel._shard_cost([labels[i] for i in s], 64) for s in shards]
+        inter = [parallel._shard_cost([labels[i] for i in range(r, len(sj), world)], 64) for r in range(world)]
+        assert max(cost) <= max(inter) + 1e-9, (world, cost, inter)
+        if world > 1:
+            assert max(cost) - min(c for c in cost if c > 0) < 40.0, (world, cost)
