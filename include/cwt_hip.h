@@ -87,6 +87,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
  *   "ols_big"      1 = rows with halo >= "ols_big_min_halo" (default 1536) and a block support <= 1/8 tile use blocks
  *                  of two workgroup tiles (default: 1 for precision 32, 0 for 64, where it measured no gain)
+ *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
  *   "ols_tile"     points per workgroup of the overlap-save rows: 8192 (default) or, precision 32 only, 16384
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)

@@ -167,6 +167,7 @@ struct cwt_plan {
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
+  int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_tile = 8192;     // points per workgroup of those rows (fp32: 8192 or 16384)
   int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
@@ -435,7 +436,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // workgroup tile of the overlap-save rows: 8192 points (512 threads); fp32 may also use 16384 (option "ols_tile")
   const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : 13;
   p->rt->ols_logp = ols_logp;
-  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && p->logN >= ols_logp + 2 &&
+  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && p->logN >= std::max(p->ols_min_logn, ols_logp + 2) &&
                       mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
@@ -1080,8 +1081,10 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   const int threads = 1 << (logP - 4);
   const size_t lds = (size_t(1) << logP) * sizeof(T);
   if (p->rt->n_ols && !x_dev) return fail(CWT_EINVAL, "overlap-save rows need the signal");
+  // (short transforms run their kernels back to back: at N = 2^16 / 2^17 the events and waits of the side streams cost
+  // more than the overlap returns -- measured 0.149 against 0.129 ms and 0.226 against 0.204 ms per 256-row transform)
   const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols) &&
-                           p->rt->n_narrow;
+                           p->rt->n_narrow && logN >= 18;
   // block spectra of the overlap-save rows: beside the two-pass chain on side stream 1 (they only need the signal)
   const bool ols_early = p->rt->n_ols && p->ols_launched;       // already queued on side stream 1 by cwt_transform
   const bool ols_side = p->rt->n_ols && !ols_early && p->ols_side && !p->profile && !p->overlap && p->rt->n_wide;
@@ -1444,6 +1447,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols") p->ols = value != 0;
   else if (k == "ols_side") p->ols_side = value != 0;
   else if (k == "ols_big") p->ols_big = value != 0;
+  else if (k == "ols_min_logn") { if (value < 15 || value > 24) return fail(CWT_EINVAL, "ols_min_logn in [15, 24]"); p->ols_min_logn = int(value); }
   else if (k == "ols_tile") { if (value != 8192 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;

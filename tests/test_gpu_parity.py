@@ -573,7 +573,7 @@ def test_overlap_save_rows_on_gpu(hip_library, name, prec, logn, n0_off):
     sj = grid(n0, 1.0, m, 96)
     real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
     x = np.random.default_rng(logn + n0_off).standard_normal(n0).astype(real)
-    plan = _hip.Plan(N, prec, max_rows=len(sj), options={"ols_big": 1})     # default: fp32 only
+    plan = _hip.Plan(N, prec, max_rows=len(sj), options={"ols_big": 1, "ols_min_logn": 15})   # defaults: fp32 only, 2^18
     xd, xh = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 2 * x.itemsize)
     Wa, Wb = (_hip.DeviceBuffer(len(sj) * n0 * 2 * x.itemsize) for _ in range(2))
     xd.upload(plan, x)

@@ -298,7 +298,7 @@ def test_overlap_save_rows(emu_library, kind, param, prec, N, n0, rows):
     ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
     out = {}
     for ols in (1, 0):
-        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"ols": ols})
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"ols": ols, "ols_min_logn": 15})
         W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
         out[ols] = (W, plan.last_split(), plan.row_classes())
         plan.close()
@@ -321,7 +321,7 @@ def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
     m = orc.Mother(orc.MORLET, 6)
     sj = grid(N, 1.0, m, 48)
     ref = orc.cwt_rows(x, 1.0, sj, m)
-    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library)
+    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library, options={"ols_min_logn": 15})
     xd, xh, Wd = DeviceBuffer(x.nbytes, lib=emu_library), DeviceBuffer(16 * N, lib=emu_library), DeviceBuffer(16 * N * len(sj), lib=emu_library)
     xd.upload(plan, x)
     plan.forward_fft(xd.ptr, N, xh.ptr)
@@ -363,7 +363,7 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
     x = np.random.default_rng(8).standard_normal(N - 77)
     m = orc.Mother(kind, param)
     sj = grid(x.size, 1.0, m, 72)
-    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=opts)
+    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=dict(opts, ols_min_logn=15))
     W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
     split, classes = plan.last_split(), plan.row_classes()
     plan.close()

@@ -195,7 +195,7 @@ def test_balanced_shards_cover_the_grid_and_even_out_the_cost(emu_library):
     m = orc.Mother(orc.MORLET, 6)
     s0 = 2 / m.flambda()
     sj = s0 * 2 ** (np.arange(96) * np.log2(N / s0) / 95)
-    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library)
+    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library, options={"ols_min_logn": 15})
     labels = plan.classify(orc.MORLET, 6.0, 1.0, sj, N, True)
     assert len(labels) == len(sj) and any(l.startswith("ols") for l in labels)
     assert not any(l.startswith("ols") for l in plan.classify(orc.MORLET, 6.0, 1.0, sj, N, False))
