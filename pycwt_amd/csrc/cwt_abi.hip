@@ -205,7 +205,9 @@ struct cwt_plan {
     int n_ols = 0, ols_first = 0;        // overlap-save rows (after the wide rows), sorted by halo class
     int ols_logp = 13;                   // log2 of their workgroup tile
     OlsClasses ols_cls;
-    long ols_wgs = 0, ols_xs_elems = 0;
+    long ols_wgs = 0, ols_xs_elems = 0, ols_gt_elems = 0;
+    void* gt_dev = nullptr;              // filter tables of the overlap-save rows, written when the table is built
+    size_t gt_bytes = 0;
     long ols_fwd_blocks[2] = {0, 0};     // blocks of P points, blocks of 2P points
     RowDesc* rows_dev = nullptr;
     RowDesc* rows_pinned = nullptr;
@@ -585,7 +587,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   p->rt->ols_first = int(p->rt->table.size());
   p->rt->n_ols = int(ols_rows.size());
   p->rt->ols_cls.n = 0;
-  p->rt->ols_wgs = p->rt->ols_xs_elems = 0;
+  p->rt->ols_wgs = p->rt->ols_xs_elems = p->rt->ols_gt_elems = 0;
   p->rt->ols_fwd_blocks[0] = p->rt->ols_fwd_blocks[1] = 0;
   if (!ols_rows.empty()) {
     // by block length, then halo
@@ -649,7 +651,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       row0 += nr;
     }
     for (int i = 0; i < OLS_MAX_CLASSES; ++i) oc.wg_first[i] = i < oc.n ? oc.c[i].wg_first : 0x7fffffff;
-    for (auto& r : ols_rows) { r.nterms = 1 << (int(r.tab_off) - ols_logp); r.tab_off = 0; }   // nterms = workgroups per block
+    long gt_off = 0;                                            // filter tables: 2^logK entries per row (k_ols_gtab)
+    for (auto& r : ols_rows) {
+      r.nterms = 1 << (int(r.tab_off) - ols_logp);               // nterms = workgroups per block
+      r.tab_off = gt_off;
+      gt_off += 1L << r.logK;
+    }
+    p->rt->ols_gt_elems = gt_off;
     p->rt->ols_wgs = wg; p->rt->ols_xs_elems = xs;
     p->rt->table.insert(p->rt->table.end(), ols_rows.begin(), ols_rows.end());
   }
@@ -1023,31 +1031,24 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
 }
 // ... and the rows themselves (k_ols_ct)
 template <typename T, int LOGP>
-int launch_ols_rows_p(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows_p(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
-  static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_MORLET>), allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_PAUL>),
-                            allow_big_lds(&k_ols_ct<T, LOGP, MOTHER_DOG>), true);
+  static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-  const dim3 block(1 << (LOGP - 4));
-  const cplx<T>* xs = static_cast<const cplx<T>*>(p->xs);
   return timed_launch(p, KC_OLS, [&] {
-#define CWT_OLS_LAUNCH(MK)                                                                                             \
-    hipLaunchKernelGGL((k_ols_ct<T, LOGP, MK>), dim3(unsigned(rt->ols_wgs)), block, lds, st, xs,                          \
-                       rt->rows_dev + rt->ols_first, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN,   \
-                       rt->ols_cls, W, long(ldw), long(ncols))
-    if (mo.kind == MOTHER_MORLET) CWT_OLS_LAUNCH(MOTHER_MORLET);
-    else if (mo.kind == MOTHER_PAUL) CWT_OLS_LAUNCH(MOTHER_PAUL);
-    else CWT_OLS_LAUNCH(MOTHER_DOG);
-#undef CWT_OLS_LAUNCH
+    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(rt->ols_wgs)), dim3(1 << (LOGP - 4)), lds, st,
+                       static_cast<const cplx<T>*>(p->xs), rt->rows_dev + rt->ols_first,
+                       static_cast<const cplx<T>*>(rt->gt_dev), static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
+                       p->logN, rt->ols_cls, W, long(ldw), long(ncols));
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows(cwt_plan* p, const Mother&, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    if (p->rt->ols_logp == 14) return launch_ols_rows_p<T, 14>(p, mo, W, ldw, ncols, st);
+    if (p->rt->ols_logp == 14) return launch_ols_rows_p<T, 14>(p, W, ldw, ncols, st);
   }
-  return launch_ols_rows_p<T, 13>(p, mo, W, ldw, ncols, st);
+  return launch_ols_rows_p<T, 13>(p, W, ldw, ncols, st);
 }
 
 template <typename T>
@@ -1383,6 +1384,7 @@ int cwt_plan_destroy(cwt_plan* p) {
                   p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
+    if (t.gt_dev) (void)hipFree(t.gt_dev);
     if (t.rows_dev) (void)hipFree(t.rows_dev);
     if (t.rows_pinned) (void)hipHostFree(t.rows_pinned);
     if (t.uploaded) (void)hipEventDestroy(t.uploaded);
@@ -1538,6 +1540,30 @@ std::vector<double> call_key(double kind, std::initializer_list<double> head, st
 
 extern "C++" {
 namespace {
+Mother mother_of(int mother, double param) {
+  Mother mo;
+  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
+  return mo;
+}
+
+// Filter tables of the overlap-save rows of the freshly uploaded row table (k_ols_gtab), on the plan's stream.
+template <typename T>
+int fill_ols_tables(cwt_plan* p, const Mother& mo) {
+  cwt_plan::RowTable* t = p->rt;
+  int rc = grow(&t->gt_dev, &t->gt_bytes, size_t(t->ols_gt_elems) * sizeof(cplx<T>), p->stream);
+  if (rc) return rc;
+  int maxk = 16;
+  for (int i = 0; i < t->n_ols; ++i) maxk = std::max(maxk, 1 << t->table[t->ols_first + i].logK);
+  const dim3 grid((maxk + 255) / 256, t->n_ols), block(256);
+  cplx<T>* gt = static_cast<cplx<T>*>(t->gt_dev);
+  const RowDesc* rows = t->rows_dev + t->ols_first;
+  if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
+  else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
+  else hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
+  HIPCHECK(hipGetLastError());
+  return CWT_OK;
+}
+
 int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, double dt, const double* scales,
                        int nrows, int64_t ldw, int64_t ncols) {
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
@@ -1561,16 +1587,12 @@ int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, 
     rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows, nullptr, nullptr, 0, -1,
                          have_signal ? ncols : 0);
     if (!rc) rc = upload_row_table(p, key);
-    if (rc) return rc;
+    if (!rc && p->rt->n_ols)
+      rc = p->prec == 64 ? fill_ols_tables<double>(p, mother_of(mother, param)) : fill_ols_tables<float>(p, mother_of(mother, param));
+    if (rc) { p->rt->key.clear(); return rc; }
   }
   set_split(p);
   return CWT_OK;
-}
-
-Mother mother_of(int mother, double param) {
-  Mother mo;
-  mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
-  return mo;
 }
 
 // Rows of W from the spectrum xhat_dev; x_dev != NULL: the real signal the spectrum came from (n0 samples), which lets

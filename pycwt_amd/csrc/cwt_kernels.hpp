@@ -970,20 +970,35 @@ __device__ __forceinline__ T profile_k(const Mother& mo, T f) {
 }
 
 // X_b[k] for signed block bin ks from the stored half spectrum (X_b[-k] = conj X_b[k]); bins outside the row's band
-// read entry 0 (any valid address) and are zeroed by ols_apply
+// read entry 0 (any valid address); their filter table entry is 0
 template <typename T>
 __device__ __forceinline__ cplx<T> ols_load(const cplx<T>* __restrict__ xb, const RowDesc& rd, int ks) {
   const bool in = unsigned(ks - rd.k_lo) < unsigned(rd.nband);
   return xb[in ? (ks < 0 ? -ks : ks) : 0];
 }
-// x * G_row[ks]
-template <typename T, int MK>
-__device__ __forceinline__ cplx<T> ols_apply(cplx<T> x, const RowDesc& rd, const Mother& mo, int ks) {
-  if (unsigned(ks - rd.k_lo) >= unsigned(rd.nband)) return mk<T>(T(0), T(0));
+// x * G_row[ks], G from the row's filter table entry g (0 outside the band)
+template <typename T>
+__device__ __forceinline__ cplx<T> ols_apply(cplx<T> x, cplx<T> g, int ks) {
   if (ks < 0) x.y = -x.y;
-  const T g = profile_k<T, MK>(mo, T(rd.a) * T(ks));
-  const T gr = g * T(rd.amp_re), gi = g * T(rd.amp_im);
-  return mk<T>(x.x * gr - x.y * gi, x.x * gi + x.y * gr);
+  return mk<T>(x.x * g.x - x.y * g.y, x.x * g.y + x.y * g.x);
+}
+
+// Filter tables of the overlap-save rows: gt[tab_off + q] = amp * profile(a * k(q)), q < K (K = 2^logK: the row's block
+// FFT length; k(q) = the band bin aliased to q, or the signed bin q itself when K = P), 0 outside the band.  Written once
+// per row table (the table is cached with it), so that the row kernel multiplies instead of evaluating one exp per band
+// bin per workgroup (K = 8192: 16 per thread, a third of that kernel's instructions).
+template <typename T, int MK>
+__global__ void k_ols_gtab(const RowDesc* __restrict__ rows, Mother mo, int logP, cplx<T>* __restrict__ gt) {
+  const RowDesc rd = rows[blockIdx.y];
+  const int K = 1 << rd.logK, q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= K) return;
+  const int ks = rd.logK == logP ? signed_bin(q, K) : rd.k_lo + ((q - rd.k_lo) & (K - 1));
+  cplx<T> g = mk<T>(T(0), T(0));
+  if (unsigned(ks - rd.k_lo) < unsigned(rd.nband)) {
+    const T v = profile_k<T, MK>(mo, T(rd.a) * T(ks));
+    g = mk<T>(v * T(rd.amp_re), v * T(rd.amp_im));
+  }
+  gt[rd.tab_off + q] = g;
 }
 
 // Half spectra of the input blocks of the classes with block length P_b = 2^(LOGM + LOGD) on M = 2^LOGM-point
@@ -1052,10 +1067,10 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
 }
 
 // Block transform with K = P: every thread filters its own 16 bins (rows whose block support exceeds P/2 bins).
-template <typename T, int LOGP, int MK>
-__device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
-                                              const cplx<T>* __restrict__ tw_all, cplx<T>* __restrict__ wout, int H,
-                                              int nlim, T* lds) {
+template <typename T, int LOGP>
+__device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, const RowDesc& rd,
+                                              const cplx<T>* __restrict__ gt, const cplx<T>* __restrict__ tw_all,
+                                              cplx<T>* __restrict__ wout, int H, int nlim, T* lds) {
   constexpr int P = 1 << LOGP, NT = P >> 4;
   using F = ct::Fft<T, LOGP, 0, false>;
   F f;
@@ -1069,7 +1084,7 @@ __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, co
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const cplx<T> v = ols_apply<T, MK>(mk<T>(re[e], im[e]), rd, mo, signed_bin(f.j + e * NT, P));
+    const cplx<T> v = ols_apply<T>(mk<T>(re[e], im[e]), gt[f.j + e * NT], signed_bin(f.j + e * NT, P));
     re[e] = v.x; im[e] = v.y;
   }
   f.run(re, im, lds, tw_all + (P - 2));
@@ -1084,8 +1099,9 @@ __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, co
 // t, n_local = TB m + t), inputs Z_r[q] = Y[k(q)] e^{2 pi i k(q) r / P} with the filtered band Y built once in LDS.
 // The host aligns the band start k_lo to a multiple of K/16, so that k(q) = k_lo + ((q - k_lo) mod K) wraps between
 // the same two slots for every thread: slots e >= ew = 16 - ((-k_lo mod K) / NT) carry an extra e^{-2 pi i K r / P}.
-template <typename T, int LOGK, int LOGP, int MK>
-__device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, const RowDesc& rd, const Mother& mo,
+template <typename T, int LOGK, int LOGP>
+__device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, const RowDesc& rd,
+                                              const cplx<T>* __restrict__ gt,
                                               const cplx<T>* __restrict__ tw_all, const TwN<T>& twn, int logN,
                                               cplx<T>* __restrict__ wout, int H, int nlim, T* lds, int logx, unsigned g) {
   // logx = log2(P_b / P), g < P_b / P: this workgroup's residues are r = g TB + t of the P_b / K of the block
@@ -1097,16 +1113,19 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
   const unsigned r = (g << LOGTB) + unsigned(f.t);
   cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
   constexpr int NQ = K > BD ? K / BD : 1;                 // band bins per thread
-  cplx<T> yv[NQ];
+  cplx<T> yv[NQ], gv[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int q = int(threadIdx.x) + i * BD;
-    if (q < K) yv[i] = ols_load<T>(xb, rd, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
+    if (q < K) {
+      yv[i] = ols_load<T>(xb, rd, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
+      gv[i] = gt[q];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int q = int(threadIdx.x) + i * BD;
-    if (q < K) ytile[q] = ols_apply<T, MK>(yv[i], rd, mo, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
+    if (q < K) ytile[q] = ols_apply<T>(yv[i], gv[i], rd.k_lo + ((q - rd.k_lo) & (K - 1)));
   }
   __syncthreads();
   const int sh = logN - LOGP - logx;
@@ -1144,9 +1163,9 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
 // All overlap-save rows of a transform in one launch: 1-D grid, class c owns workgroups [wg_first, next wg_first);
 // inside a class the 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of a block back to back, so that
 // a block spectrum is fetched into one L2 once and read there by every row.
-template <typename T, int LOGP, int MK>
+template <typename T, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
-k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mother mo,
+k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ gtab,
          const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, OlsClasses cls, cplx<T>* __restrict__ W, long ldw,
          long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
@@ -1168,15 +1187,16 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, Mothe
   const long left = ncols - col0;
   const int nlim = left < L ? int(left) : L;
   cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
+  const cplx<T>* gt = gtab + rd.tab_off;
 #define CWT_OLS_CASE(LK)                                                                            \
   case LK:                                                                                           \
-    if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP, MK>(xb, rd, mo, tw_all, twn, logN, wout, H, nlim, lds, logx, g); \
-    else ols_full_body<T, LOGP, MK>(xb, rd, mo, tw_all, wout, H, nlim, lds);                        \
+    if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP>(xb, rd, gt, tw_all, twn, logN, wout, H, nlim, lds, logx, g); \
+    else ols_full_body<T, LOGP>(xb, rd, gt, tw_all, wout, H, nlim, lds);                            \
     break;
   switch (rd.logK) {
     CWT_OLS_CASE(4) CWT_OLS_CASE(5) CWT_OLS_CASE(6) CWT_OLS_CASE(7) CWT_OLS_CASE(8) CWT_OLS_CASE(9)
     CWT_OLS_CASE(10) CWT_OLS_CASE(11) CWT_OLS_CASE(12) CWT_OLS_CASE(13)
-    default: ols_full_body<T, LOGP, MK>(xb, rd, mo, tw_all, wout, H, nlim, lds); break;
+    default: ols_full_body<T, LOGP>(xb, rd, gt, tw_all, wout, H, nlim, lds); break;
   }
 #undef CWT_OLS_CASE
 }
