@@ -1044,7 +1044,7 @@ int launch_ols_rows_p(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipSt
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, const Mother&, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
     if (p->rt->ols_logp == 14) return launch_ols_rows_p<T, 14>(p, W, ldw, ncols, st);
   }
@@ -1154,7 +1154,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
     }
     if (ols_side) HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
     else rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream);
-    if (!rc) rc = launch_ols_rows<T>(p, mo, W, ldw, ncols, p->stream);
+    if (!rc) rc = launch_ols_rows<T>(p, W, ldw, ncols, p->stream);
     if (rc) return rc;
   }
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
@@ -1609,14 +1609,13 @@ int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, 
 // The overlap-save rows need the signal only: cwt_transform queues them on side stream 1 BEFORE the forward FFT, so
 // that they run beside it and beside the two-pass chain; rows_impl then skips them and joins the stream at its end.
 template <typename T>
-int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, void* W_dev, int64_t ldw,
-                     int64_t ncols) {
+int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, int64_t ldw, int64_t ncols) {
   int rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
   rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);
-  if (!rc) rc = launch_ols_rows<T>(p, mo, static_cast<cplx<T>*>(W_dev), ldw, ncols, p->side[1]);
+  if (!rc) rc = launch_ols_rows<T>(p, static_cast<cplx<T>*>(W_dev), ldw, ncols, p->side[1]);
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   p->ols_launched = 1;
@@ -1652,8 +1651,8 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   const Mother mo = mother_of(mother, param);
   p->ols_launched = 0;
   if (p->rt->n_ols && p->ols_early && !p->profile && !p->overlap) {
-    rc = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, mo, W_dev, ldw, ncols)
-                       : launch_ols_early<float>(p, x_dev, n0, mo, W_dev, ldw, ncols);
+    rc = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
+                       : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
     if (rc) return rc;
   }
   rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
