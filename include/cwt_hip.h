@@ -257,7 +257,9 @@ int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_
  * tests and bench.py use it to report the worst row per kernel class.                                          */
 int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
 /* The same codes for a transform that has not run yet: classifies `nrows` scales exactly as cwt_transform
- * (with_signal = 1) or cwt_transform_rows (0) with these arguments would, without launching anything.
+ * (with_signal = 1) or cwt_transform_rows (0) with these arguments would.  No transform runs; the classified table is
+ * kept in the plan's cache (its upload and, for overlap-save rows, its filter tables are queued on the plan's stream), so a
+ * following transform call with the same arguments finds it ready.
  * pycwt_amd.parallel uses it to cut a scale grid into cost-balanced contiguous shards.                        */
 int cwt_plan_classify(cwt_plan* plan, int mother, double param, double dt, const double* scales_host, int nrows,
                       int64_t ncols, int with_signal, int* codes);

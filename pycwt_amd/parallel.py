@@ -55,8 +55,11 @@ def _shard_cost(labels, precision):
             seen.add(kind)
             total += fixed
         total += per
-        if kind == "narrow" and "/t" in lab:
-            total += c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
+        if kind == "narrow" and "/K" in lab:             # longer transforms per residue, shorter store segments
+            k = int(lab.split("/K")[1].split("/")[0])
+            total += per * (0.11 if k >= 512 else 0.04 if k >= 128 else -0.04)
+            if "/t" in lab:
+                total += c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
     if seen - {"ols"}:
         total += c["fwd"]                 # some row needs the spectrum
     return total
