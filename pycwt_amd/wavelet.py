@@ -24,6 +24,9 @@ from .mothers import DOG, MexicanHat, Morlet, Paul
 _MOTHERS = {"morlet": Morlet, "paul": Paul, "dog": DOG, "mexicanhat": MexicanHat}
 _plans: dict = {}
 _plans_lock = threading.Lock()
+# cwt_plan_set_option pairs applied to every plan this module creates from now on (tuning / tests), e.g.
+# {"ols": 0} = N-point transform of every row, {"ols_min_logn": 15} = overlap-save rows from N = 2^15 on
+PLAN_OPTIONS: dict = {}
 
 
 def _check_parameter_wavelet(wavelet):
@@ -48,7 +51,7 @@ def _plan(nfft: int, precision: int, device: int, rows: int) -> _hip.Plan:
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None or plan.max_rows < rows:
-            plan = _hip.Plan(nfft, precision, max_rows=max(1024, rows), device=device)
+            plan = _hip.Plan(nfft, precision, max_rows=max(1024, rows), device=device, options=dict(PLAN_OPTIONS))
             _plans[key] = plan
         return plan
 

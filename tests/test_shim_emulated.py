@@ -257,3 +257,31 @@ def test_unpadded_lengths_against_the_oracle(emulated, n0):
         per_row, _ = row_errors(out[0], ref[0])
         assert per_row.max() < 1e-11, (n0, name, per_row.max())
         np.testing.assert_allclose(out[4], ref[4], rtol=0, atol=1e-11 * max(np.abs(ref[4]).max(), 1e-300) if ref[4].size else 0)
+
+
+@pytest.mark.parametrize("name,dt,n0", [("morlet", 0.25, 40000), ("dog", 3.0, 32768), ("mexicanhat", 0.5, 50001)])
+def test_drop_in_call_with_overlap_save_rows(emulated, monkeypatch, name, dt, n0):
+    """The drop-in call with time-compact rows on the overlap-save kernels (forced on at these short lengths through
+    wavelet.PLAN_OPTIONS; by default the form starts at N = 2^18): cwt, icwt and the device-resident variant against
+    the oracle at dt != 1, with a ragged length, default and explicit scale grids."""
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "PLAN_OPTIONS", {"ols_min_logn": 15})
+    x = np.random.default_rng(n0).standard_normal(n0)
+    mother = wavelet._check_parameter_wavelet(name)
+    m = orc.Mother(*wavelet._device_id(mother))
+    W, sj, freqs, coi, fft, fftfreqs = pycwt_amd.cwt(x, dt, 1 / 4, -1, -1, name)
+    plan = next(iter(wavelet._plans.values()))
+    assert plan.last_split()["ols"] >= 4, plan.last_split()
+    N = 1 << int(np.ceil(np.log2(n0)))
+    ref = orc.cwt_rows(x, dt, sj, m, N=N)[:, :n0]
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < 1e-12, (per_row.argmax(), per_row.max())
+    np.testing.assert_allclose(fft, (np.fft.fft(x, n=N)[1:N // 2]) / np.sqrt(N), rtol=0, atol=1e-12 * np.abs(fft).max())
+    T = pycwt_amd.cwt_device(x, dt, 1 / 4, -1, -1, name)
+    np.testing.assert_allclose(T.global_power(), (np.abs(ref) ** 2).mean(axis=1), rtol=1e-11)
+    iw = T.icwt(1 / 4)
+    np.testing.assert_allclose(iw, pycwt_amd.icwt(W, sj, dt, 1 / 4, mother), rtol=1e-11, atol=1e-12)
+    sel = sj[3:40:4]
+    W2 = pycwt_amd.cwt(x, dt, wavelet=name, freqs=1 / (mother.flambda() * sel))[0]
+    per_row, _ = row_errors(W2, ref[3:40:4])
+    assert per_row.max() < 1e-12
