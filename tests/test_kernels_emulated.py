@@ -287,6 +287,9 @@ def test_pass_b_with_prefetched_tiles(emu_library, tiles, prec):
     (orc.DOG, 2, 32, 1 << 16, 65000, 48),             # two-sided spectrum, K = 16384 (full block)
     (orc.DOG, 2, 64, 1 << 16, 50000, 40),
     (orc.DOG, 1, 64, 1 << 15, 32768, 20),             # odd order: imaginary mother constant
+    (orc.MORLET, 2.0, 64, 1 << 16, (1 << 15) + 1, 40),   # low f0: the band reaches far into negative frequencies; the
+                                                       # padded half of the transform is never written (blocks cover n0)
+    (orc.DOG, 6, 32, 1 << 16, 65536, 40),
 ])
 def test_overlap_save_rows(emu_library, kind, param, prec, N, n0, rows):
     """Rows whose filter is not clipped at Nyquist and whose wavelet fits a quarter tile in time are computed block
