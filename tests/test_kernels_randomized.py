@@ -72,3 +72,49 @@ def test_random_geometry_matches_oracle(emu_library, case):
     # row of this signal would carry (|W| <= sqrt(2 pi s/dt) * max|psi_ft| * ||x||_1 / ... ).
     floor = (1e-15 if prec == 64 else 1e-7) * np.sqrt(2 * np.pi * sj / 0.7) * np.abs(x).sum()
     assert (err <= tol * scale + floor).all(), (opts, err, scale)
+
+
+@st.composite
+def ols_cases(draw):
+    """Lengths at which the overlap-save form is allowed (forced down to 2^15 for the emulator), scales drawn where
+    time-compact rows live (a few samples to a quarter tile of halo) plus a few outside, unsorted and repeated."""
+    logn = draw(st.integers(15, 16))
+    N = 1 << logn
+    n0 = draw(st.integers(N // 2 + 1, N))
+    kind, param = draw(st.sampled_from([(orc.MORLET, 6), (orc.MORLET, 2.5), (orc.MORLET, 9.0), (orc.DOG, 2), (orc.DOG, 1),
+                                        (orc.DOG, 7), (orc.PAUL, 4), (orc.PAUL, 2)]))
+    prec = 32 if kind == orc.PAUL else draw(st.sampled_from([64, 32]))
+    nrows = draw(st.integers(1, 14))
+    expo = draw(st.lists(st.floats(0.5, 9.5), min_size=nrows, max_size=nrows))
+    dt = draw(st.sampled_from([1.0, 0.25, 7.0]))
+    opts = {"ols_min_logn": 15}
+    if draw(st.booleans()):
+        opts["ols_big"] = draw(st.integers(0, 1))
+        opts["ols_fwd_weight"] = draw(st.sampled_from([0, 100, 1000]))
+        opts["ols_max_halo"] = draw(st.sampled_from([0, 256, 1024]))
+        opts["ols_side"] = draw(st.integers(0, 1))
+        opts["ols_early"] = draw(st.integers(0, 1))
+        if prec == 32:
+            opts["ols_tile"] = draw(st.sampled_from([8192, 16384]))
+    return N, n0, kind, param, dt * np.array([2.0 ** e for e in expo]), dt, prec, opts, draw(st.integers(0, 2 ** 31))
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(ols_cases())
+def test_random_overlap_save_rows_match_oracle(emu_library, case):
+    N, n0, kind, param, sj, dt, prec, opts, seed = case
+    m = orc.Mother(kind, param)
+    with np.errstate(all="ignore"):
+        sj = sj[~np.isnan(m.psi_ft(sj * (-np.pi / dt)))]
+    if sj.size == 0:
+        return
+    x = np.random.default_rng(seed).standard_normal(n0)
+    plan = _hip.Plan(N, prec, max_rows=16, lib=emu_library, options=opts)
+    W, _ = plan.execute_host(x, kind, param, dt, sj, want_xhat=False)
+    split, classes = plan.last_split(), plan.row_classes()
+    plan.close()
+    ref = orc.cwt_rows(x, dt, sj, m, N=N)[:, :n0]
+    tol = 1e-11 if prec == 64 else 5e-5
+    err = np.abs(W - ref).max(axis=1)
+    scale = np.abs(ref).max(axis=1)
+    assert (err <= tol * scale).all(), (opts, split, [(c, e / s) for c, e, s in zip(classes, err, scale)])
