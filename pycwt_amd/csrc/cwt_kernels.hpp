@@ -1177,18 +1177,21 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int P = 1 << LOGP;
-  int c = -1;
+  // this workgroup's class: every class record is read from the kernel arguments at a fixed address (one round of scalar
+  // loads for all 16) and selected with uniform compares -- no load whose address depends on an earlier load
+  OlsClass oc = cls.c[0];
 #pragma unroll
-  for (int i = 0; i < OLS_MAX_CLASSES; ++i) c += int(blockIdx.x) >= cls.wg_first[i];   // independent compares, no loop-carried loads
-  const unsigned local = blockIdx.x - unsigned(cls.c[c].wg_first);
-  const int logx = cls.c[c].logb - LOGP;
+  for (int i = 1; i < OLS_MAX_CLASSES; ++i)
+    if (int(blockIdx.x) >= cls.wg_first[i]) oc = cls.c[i];
+  const unsigned local = blockIdx.x - unsigned(oc.wg_first);
+  const int logx = oc.logb - LOGP;
   const unsigned g = (local >> 3) & ((1u << logx) - 1u);      // which part of the block's residues
-  const unsigned seq = local >> (3 + logx), nr = unsigned(cls.c[c].nrows);
+  const unsigned seq = local >> (3 + logx), nr = unsigned(oc.nrows);
   const unsigned blk = (seq / nr) * 8u + (local & 7u);
-  if (blk >= unsigned(cls.c[c].nblocks)) return;
-  const RowDesc rd = rows[cls.c[c].row_first + int(seq % nr)];
-  const int H = cls.c[c].halo, L = (P << logx) - 2 * H;
-  const cplx<T>* xb = xs + cls.c[c].xs_off + long(blk) * ((P << logx) / 2 + 8);
+  if (blk >= unsigned(oc.nblocks)) return;
+  const RowDesc rd = rows[oc.row_first + int(seq % nr)];
+  const int H = oc.halo, L = (P << logx) - 2 * H;
+  const cplx<T>* xb = xs + oc.xs_off + long(blk) * ((P << logx) / 2 + 8);
   const long col0 = long(blk) * L;
   const long left = ncols - col0;
   const int nlim = left < L ? int(left) : L;
