@@ -100,7 +100,20 @@ def balanced_shards(labels, world: int, precision: int = 64):
         else:
             hi_t = mid
     cuts = cuts_for(hi_t)
-    return [np.arange(a, b) for a, b in cuts]
+    # The greedy fill leaves the slack in the last shard and may strand one or two rows of a kernel class in a shard
+    # (a one-row launch of the K = 2048 kernel costs 25 us): move every boundary by up to 4 rows where that lowers the
+    # larger of the two neighbouring shards.
+    bounds = [a for a, _ in cuts] + [n]
+    for _ in range(3):
+        for i in range(1, world):
+            lo, hi = bounds[i - 1], bounds[i + 1]
+            best, best_cost = bounds[i], None
+            for b in range(max(lo, bounds[i] - 4), min(hi, bounds[i] + 4) + 1):
+                cost = max(_shard_cost(labels[lo:b], precision), _shard_cost(labels[b:hi], precision))
+                if best_cost is None or cost < best_cost - 1e-9:
+                    best, best_cost = b, cost
+            bounds[i] = best
+    return [np.arange(bounds[i], bounds[i + 1]) for i in range(world)]
 
 
 class HipEngine:
