@@ -15,6 +15,8 @@ sharding / collective logic under the gloo backend.
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from . import _hip
@@ -66,6 +68,13 @@ def _shard_cost(labels, precision):
 
 
 def balanced_shards(labels, world: int, precision: int = 64):
+    """See `_balanced_shards`; results are cached per (labels, world, precision): repeated transforms of one scale grid
+    (the normal use) pay the search once."""
+    return [np.array(s) for s in _balanced_shards(tuple(labels), world, precision)]
+
+
+@functools.lru_cache(maxsize=64)
+def _balanced_shards(labels, world: int, precision: int = 64):
     """Cuts the scale grid (rows in scale order, `labels` = their kernel classes from `Plan.classify`) into `world`
     CONTIGUOUS shards of equal estimated cost.  Against interleaving (row j -> rank j mod G) a rank then runs few
     kernel classes with many rows each instead of every class with a handful -- at 8 ranks the interleaved share
