@@ -95,6 +95,18 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
+/* Accuracy target of the transform: the bound, per row of W, on max|W - W_exact| / max|W_exact| that the fast forms
+ * of the path may spend (W_exact = what wavelet.py:91-106 computes in exact arithmetic).  Three truncations are derived
+ * from it: the filter support (bins of psi_ft below rel_tol/10 of its peak count as zero: band limiting), the
+ * overlap-save halo (neglected L1 mass of |psi| <= rel_tol/10) and the "not clipped at Nyquist" test of the
+ * overlap-save rows (profile at the Nyquist bins <= rel_tol of its peak).  0 selects the default: 1e-9 for
+ * precision 64 and 3e-5 for precision 32 (measured worst-row errors 2e-10 and 5e-6: more than two orders of magnitude
+ * inside the 1e-6 / 1e-3 parity bars of the path); 1e-16 makes every truncation smaller than fp64 rounding (results then agree with the reference to
+ * ~3e-15).  Rounding of the arithmetic itself (~1e-15 / ~3e-6) comes on top.  Also reachable as the option
+ * "tolerance_neglog10" (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces
+ * the default of new plans (the test-suite sets 1e-16 where it checks the kernels' arithmetic).  Measured error and speed per target: profiles/r03_tolerance_sweep.txt. */
+int cwt_plan_set_tolerance(cwt_plan* plan, double rel_tol);
+int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 /* Block the host until everything queued by this plan has finished. */
 int cwt_plan_sync(cwt_plan* plan);
 

@@ -67,6 +67,8 @@ SYMBOLS = [
                                     C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("cwt_plan_set_tolerance", C.c_int, [_P, C.c_double]),
+    ("cwt_plan_get_tolerance", C.c_int, [_P, C.POINTER(C.c_double)]),
 ]
 
 
@@ -149,7 +151,10 @@ class Plan:
         self.lib.check(self.lib.cwt_plan_create(C.byref(h), device, self.nfft, self.precision, self.max_rows))
         self.h = h
         for k, v in (options or {}).items():
-            self.set_option(k, v)
+            if k == "tolerance":
+                self.set_tolerance(v)
+            else:
+                self.set_option(k, v)
 
     def close(self):
         lock = getattr(self, "lock", None)
@@ -168,6 +173,17 @@ class Plan:
     @_locked
     def set_option(self, key: str, value: int):
         self.lib.check(self.lib.cwt_plan_set_option(self.h, key.encode(), int(value)))
+
+    @_locked
+    def set_tolerance(self, rel_tol: float):
+        """Accuracy target per row of W (max|dW| / max|W|); 0 = the precision's default (see cwt_plan_set_tolerance)."""
+        self.lib.check(self.lib.cwt_plan_set_tolerance(self.h, float(rel_tol)))
+
+    @_locked
+    def tolerance(self) -> float:
+        v = C.c_double(0)
+        self.lib.check(self.lib.cwt_plan_get_tolerance(self.h, C.byref(v)))
+        return v.value
 
     @_locked
     def set_stream(self, stream_handle: int):

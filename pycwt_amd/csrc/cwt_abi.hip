@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -173,6 +174,9 @@ struct cwt_plan {
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
   int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
   double ols_fwd_weight = 1.0;   // cost of one block spectrum in units of one row's block transform (class grouping)
+  // Accuracy target of a row, max|dW| / max|W| against the exact transform (cwt_plan_set_tolerance; 0 = the precision's
+  // default).  The three truncations of the fast forms are derived from it (see tolerances()).
+  double tolerance = 0.0;
   // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
   unsigned long long* stamps = nullptr;
   int64_t stamp_cap = 0, stamp_next = 0;
@@ -238,6 +242,25 @@ struct cwt_plan {
 };
 
 namespace {
+
+// Default accuracy targets: three orders of magnitude inside the parity bars of the path (1e-6 relative in fp64, 1e-3 in
+// fp32); the measured worst-row errors per target are in profiles/r03_tolerance_sweep.txt.
+constexpr double kDefaultTolerance64 = 1e-9, kDefaultTolerance32 = 3e-5;
+// The truncations that make the fast forms possible, all derived from the one accuracy target tol of the plan:
+//   support  bins whose profile is below this fraction of its peak are treated as exactly zero (band limiting);
+//   halo     neglected fraction of the L1 mass of |psi| beyond the overlap-save halo (a bound on the relative error);
+//   clip     a row counts as "not clipped at Nyquist" (time-compact wavelet) if its profile at the Nyquist bins is below
+//            this fraction of its peak (measured error of the overlap-save form: about a tenth of the fraction).
+// Each is floored where the arithmetic's own rounding takes over.
+struct Tolerances { double support, halo, clip; };
+Tolerances tolerances(const cwt_plan* p) {
+  const double t = p->tolerance > 0 ? p->tolerance : (p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32);
+  Tolerances r;
+  r.support = std::max(t * 0.1, p->prec == 64 ? 1e-18 : 1e-9);
+  r.halo = std::max(t * 0.1, p->prec == 64 ? 1e-17 : 5e-7);
+  r.clip = std::max(t, p->prec == 64 ? 1e-16 : 1e-8);
+  return r;
+}
 
 template <typename T>
 const cplx<T>* tw_table(const cwt_plan* p, int logL) {
@@ -350,6 +373,19 @@ void profile_support(int mother, double p, double eps, double* f_lo, double* f_h
   }
 }
 
+// log(profile(f) / peak of the profile) for the built-in mothers (-inf where the profile is 0)
+double profile_log_rel(int mother, double p, double f) {
+  const double ninf = -std::numeric_limits<double>::infinity();
+  if (mother == MOTHER_MORLET) return -0.5 * (f - p) * (f - p);
+  if (mother == MOTHER_PAUL) return f > 0 ? h_paul(f, p) - (p > 0 ? h_paul(p, p) : 0.0) : ninf;
+  const double fp = std::sqrt(p > 0 ? p : 0.0);
+  if (p > 0 && f == 0) return ninf;
+  return h_dog(std::fabs(f), p) - (p > 0 ? h_dog(fp, p) : 0.0);
+}
+double profile_peak_f(int mother, double p) {
+  return mother == MOTHER_MORLET ? p : mother == MOTHER_PAUL ? p : std::sqrt(p > 0 ? p : 0.0);
+}
+
 // Overlap-save rows: the wavelet of scale s is treated as zero beyond |t| > c_H * s, c_H chosen so that the neglected
 // tail carries less than eps of the L1 mass of |psi| (the bound on the relative error of any output sample):
 //   Morlet, DOG m: |psi(eta)| = |He_m(eta)| exp(-eta^2/2) (m = 0 for Morlet) -- numerical quadrature;
@@ -419,8 +455,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int64_t N = p->N;
   double f_lo = 0, f_hi = 0;
   if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
-  if (mother != MOTHER_TABLE)
-  profile_support(mother, param, p->prec == 64 ? 1e-18 : 1e-9, &f_lo, &f_hi);
+  const Tolerances tol = tolerances(p);
+  if (mother != MOTHER_TABLE) profile_support(mother, param, tol.support, &f_lo, &f_hi);
 
   const int logP = std::min(p->log_wg_points, p->logN);
   const bool use_small = p->logN <= p->loglmax;
@@ -443,11 +479,11 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
   const bool ols_big = ols_ok && p->ols_big && ols_logp == 13 && p->logN >= ols_logp + 3;   // blocks of 2P points
-  const double ols_ch = ols_ok ? time_halo_factor(mother, param, p->prec == 64 ? 1e-17 : 5e-7) : 0.0;
+  const double ols_ch = ols_ok ? time_halo_factor(mother, param, tol.halo) : 0.0;
   // "not clipped at Nyquist": the profile at the Nyquist bins is below this fraction of its peak (the jump there is what
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
   double fc_lo = 0, fc_hi = 0;
-  if (ols_ok) profile_support(mother, param, p->prec == 64 ? 1e-14 : 1e-8, &fc_lo, &fc_hi);
+  if (ols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows, ols_rows;
   for (int j = 0; j < nrows; ++j) {
     if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
@@ -458,7 +494,25 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     // batched signals: row j belongs to signal j / rows_per_signal, whose spectrum starts at spec_ld * that
     rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
-    double klo = std::ceil(f_lo / rd.a), khi = std::floor(f_hi / rd.a);
+    double row_lo = f_lo, row_hi = f_hi;
+    if (mother != MOTHER_TABLE) {
+      // The support threshold is meant relative to the largest value the filter takes ON THE ROW'S BINS.  Where the bins
+      // are coarser than the profile (a >~ 1: the largest scales) that is far below the profile's own peak: the
+      // threshold follows it, or the row would lose the few bins that carry all of its (tiny) energy.
+      const double kc = profile_peak_f(mother, param) / rd.a;
+      double best = -std::numeric_limits<double>::infinity();
+      for (double k : {std::floor(kc), std::ceil(kc), -std::floor(kc), -std::ceil(kc)}) {
+        if (mother == MOTHER_PAUL) k = std::max(k, 1.0);
+        if (mother == MOTHER_MORLET && k < 0) continue;
+        k = std::min(std::max(k, -double(N / 2)), double(N / 2 - 1));
+        best = std::max(best, profile_log_rel(mother, param, rd.a * k));
+      }
+      if (std::isfinite(best) && best < std::log(0.25)) {
+        const double eps_row = std::max(tol.support * std::exp(best), 1e-300);
+        profile_support(mother, param, eps_row, &row_lo, &row_hi);
+      }
+    }
+    double klo = std::ceil(row_lo / rd.a), khi = std::floor(row_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
     const bool unclipped = ols_ok && std::ceil(fc_lo / rd.a) > -double(N / 2) &&      // F_j vanishes at the Nyquist bins
                            std::floor(fc_hi / rd.a) < double(N / 2 - 1);
@@ -1333,6 +1387,10 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->max_rows = max_rows;
   p->log_wg_points = precision == 64 ? 13 : 14;
   p->narrow_terms = precision == 64 ? 4 : 8;      // see the cost table in build_row_table
+  if (const char* e = std::getenv("CWT_TOLERANCE")) {   // default accuracy target of plans created from here on
+    const double t = std::atof(e);
+    if (t > 0 && t <= 1e-2) p->tolerance = t;
+  }
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
@@ -1455,9 +1513,27 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_early") p->ols_early = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
+  else if (k == "tolerance_neglog10") {   // integer alias of cwt_plan_set_tolerance for option sweeps: 10^-value; 0 = default
+    if (value < 0 || value > 18) return fail(CWT_EINVAL, "tolerance_neglog10 in [0, 18]");
+    p->tolerance = value ? std::pow(10.0, -double(value)) : 0.0;
+  }
   else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);
+}
+
+int cwt_plan_set_tolerance(cwt_plan* p, double rel_tol) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  if (!(rel_tol >= 0) || rel_tol > 1e-2) return fail(CWT_EINVAL, "tolerance must be in [0, 1e-2] (0 = default)");
+  for (auto& t : p->slots) t.key.clear();   // the classification depends on it
+  p->tolerance = rel_tol;
+  return CWT_OK;
+}
+
+int cwt_plan_get_tolerance(cwt_plan* p, double* rel_tol) {
+  if (!p || !rel_tol) return fail(CWT_EINVAL, "NULL argument");
+  *rel_tol = p->tolerance > 0 ? p->tolerance : (p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32);
+  return CWT_OK;
 }
 
 int cwt_plan_sync(cwt_plan* p) {

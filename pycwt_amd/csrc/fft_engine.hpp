@@ -184,7 +184,11 @@ __device__ __forceinline__ void twiddle_chain(T (&re)[R], T (&im)[R], T wr, T wi
     const T x = re[m], y = im[m];
     re[m] = x * pr - y * pi;
     im[m] = x * pi + y * pr;
+#if defined(CWT_LAB) && defined(CWT_ABLATE_TW)
+    if (false) {                 // timing only: what the running-product twiddles cost
+#else
     if (m + 1 < R) {
+#endif
       const T nr = pr * wr - pi * wi;
       pi = pr * wi + pi * wr;
       pr = nr;

@@ -1,0 +1,89 @@
+"""The plan's accuracy target (cwt_plan_set_tolerance): the truncations of the fast forms -- filter support,
+overlap-save halo, Nyquist-clip test -- follow it, the measured error stays inside it, and the product defaults
+(1e-9 in fp64, 3e-5 in fp32) sit two to three orders of magnitude inside north_star's parity bars (1e-6 / 1e-3).
+CPU emulation of the real kernels; the GPU repeat at N = 2^20 is tests/test_gpu_parity.py::test_tolerance_on_gpu."""
+import numpy as np
+import pytest
+
+from conftest import row_errors
+from oracle import cwt_oracle as orc
+from pycwt_amd import _hip
+from test_kernels_emulated import grid
+
+N = 1 << 16
+
+
+def run(lib, kind, param, prec, tol, sj, x, **opts):
+    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=lib, options=dict(opts, ols_min_logn=15, tolerance=tol))
+    assert plan.tolerance() == pytest.approx(tol if tol else (1e-9 if prec == 64 else 3e-5))
+    W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+    classes = plan.row_classes()
+    plan.close()
+    return W, classes
+
+
+@pytest.mark.parametrize("kind,param,prec,tols", [
+    (orc.MORLET, 6, 64, (1e-15, 1e-12, 1e-9, 1e-7)),
+    (orc.DOG, 2, 64, (1e-12, 1e-9)),
+    (orc.PAUL, 4, 64, (1e-12, 1e-9)),
+    (orc.DOG, 2, 32, (1e-5, 1e-4)),
+    (orc.PAUL, 4, 32, (3e-5, 3e-4)),
+])
+def test_error_stays_inside_the_target(emu_library, monkeypatch, kind, param, prec, tols):
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    x = np.random.default_rng(11).standard_normal(N - 123)
+    m = orc.Mother(kind, param)
+    sj = grid(x.size, 1.0, m, 64)
+    keep = np.ones(len(sj), bool)                      # grid() already leaves out the rows the reference drops
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size]
+    rounding = 1e-14 if prec == 64 else 8e-6          # what the arithmetic itself contributes (measured: 3e-15 / 3.5e-6)
+    wide = []
+    for tol in tols:
+        W, classes = run(emu_library, kind, param, prec, tol, sj, x)
+        per_row, _ = row_errors(W[keep], ref[keep])
+        assert per_row.max() < tol + rounding, (tol, per_row.argmax(), per_row.max())
+        wide.append(sum(c.startswith("two_pass") for c in classes))
+    assert wide == sorted(wide, reverse=True), wide       # a looser target never needs more two-pass rows
+
+
+def test_product_defaults(emu_library, monkeypatch):
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    x = np.random.default_rng(12).standard_normal(N)
+    for kind, param, prec, bar in ((orc.MORLET, 6, 64, 1e-8), (orc.DOG, 2, 32, 1e-5)):
+        m = orc.Mother(kind, param)
+        sj = grid(N, 1.0, m, 48)
+        W, _ = run(emu_library, kind, param, prec, 0.0, sj, x)
+        per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N))
+        assert per_row.max() < bar, per_row.max()        # 1/100 of north_star's bar
+
+
+def test_environment_sets_the_default_and_bad_values_are_refused(emu_library, monkeypatch):
+    monkeypatch.setenv("CWT_TOLERANCE", "1e-12")
+    plan = _hip.Plan(1024, 64, max_rows=4, lib=emu_library)
+    assert plan.tolerance() == pytest.approx(1e-12)
+    plan.set_tolerance(1e-7)
+    assert plan.tolerance() == pytest.approx(1e-7)
+    plan.set_option("tolerance_neglog10", 10)
+    assert plan.tolerance() == pytest.approx(1e-10)
+    for bad in (-1.0, 0.5, float("nan")):
+        with pytest.raises(_hip.HipError):
+            plan.set_tolerance(bad)
+    plan.close()
+
+
+@pytest.mark.parametrize("kind,param,prec", [(orc.DOG, 2, 32), (orc.MORLET, 6, 64), (orc.PAUL, 4, 32)])
+def test_largest_scales_keep_their_few_bins(emu_library, monkeypatch, kind, param, prec):
+    """Scales so large that the filter's peak falls between bins 0 and 1: the row's energy sits in one or two bins far
+    down the flank of the profile.  The support threshold follows the largest value ON the bins (found on the GPU at
+    config 3: rows 253-255 of the DOG grid came out as zeros at a loose target)."""
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    x = np.random.default_rng(13).standard_normal(N)
+    m = orc.Mother(kind, param)
+    # (fp32 stops at 2N: beyond, exp(-f) / exp(-f^2/2) at bin 1 leaves the float range and the row is 0 by underflow)
+    sj = N * np.array([0.25, 0.5, 1.0, 2.0, 3.0][:5 if prec == 64 else 4])
+    keep = ~orc.dropped_rows(sj, 1.0, m)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)
+    tol = 1e-7 if prec == 64 else 1e-4
+    W, _ = run(emu_library, kind, param, prec, tol, sj, x)
+    per_row, _ = row_errors(W[keep], ref[keep])
+    assert per_row.max() < tol + (1e-13 if prec == 64 else 2e-5), per_row
