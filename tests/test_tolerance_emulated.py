@@ -71,7 +71,7 @@ def test_environment_sets_the_default_and_bad_values_are_refused(emu_library, mo
     plan.close()
 
 
-@pytest.mark.parametrize("kind,param,prec", [(orc.DOG, 2, 32), (orc.MORLET, 6, 64), (orc.PAUL, 4, 32)])
+@pytest.mark.parametrize("kind,param,prec", [(orc.DOG, 2, 32), (orc.MORLET, 6, 64), (orc.DOG, 2, 64)])   # (Paul: the reference turns these rows into NaN)
 def test_largest_scales_keep_their_few_bins(emu_library, monkeypatch, kind, param, prec):
     """Scales so large that the filter's peak falls between bins 0 and 1: the row's energy sits in one or two bins far
     down the flank of the profile.  The support threshold follows the largest value ON the bins (found on the GPU at
