@@ -136,7 +136,7 @@ class Workload:
     """One BASELINE configuration on this rank: the signal, this rank's rows (j = rank mod world) of a
     `rows_total`-row scale grid, the device buffers and the plan."""
 
-    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced"):
+    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced", pipeline=1):
         from pycwt_amd import _hip
         torch = rt.torch
         self.rt, self.config = rt, config
@@ -169,14 +169,22 @@ class Workload:
         self.xhat = torch.empty(self.N, dtype=cplx_t, device=rt.dev)
         self.W = torch.empty((max(len(self.sj), 1), self.N), dtype=cplx_t, device=rt.dev)
         self.plan.set_stream(rt.stream_handle())
+        # --pipeline P > 1 (diagnostic): P signals in flight, step i on lane i mod P = its own plan, stream and W
+        self.lanes = [(self.plan, None, self.W, self.xhat)]
+        for _ in range(1, pipeline):
+            pl = _hip.Plan(self.N, self.prec, max_rows=rows_total, device=rt.device_index, lib=rt.lib, options=self.opts)
+            st = torch.cuda.Stream(device=rt.dev)
+            pl.set_stream(st.cuda_stream)
+            self.lanes.append((pl, st, torch.empty_like(self.W), torch.empty_like(self.xhat)))
         self.tolerance = self.plan.tolerance()
         self.sharded = rt.shard[1] > 1
 
-    def compute(self, buf):
+    def compute(self, buf, i=0):
         if len(self.sj):   # forward FFT + every row of W in one call (wavelet.py:91-106); a rank of a sharded transform
             # has no use for the spectrum itself (None: kept in plan scratch, skipped if none of its rows needs it)
-            self.plan.transform(buf.data_ptr(), self.N, self.kind, self.param, self.dt, self.sj,
-                                None if self.sharded else self.xhat.data_ptr(), self.W.data_ptr(), self.N, self.N)
+            plan, _, W, xhat = self.lanes[i % len(self.lanes)]
+            plan.transform(buf.data_ptr(), self.N, self.kind, self.param, self.dt, self.sj,
+                           None if self.sharded else xhat.data_ptr(), W.data_ptr(), self.N, self.N)
 
     def run_steps(self, count):
         """`count` steps.  With more than one rank the broadcast of step i+1 is issued (async, on RCCL's own
@@ -189,7 +197,7 @@ class Workload:
             if rt.use_dist:
                 pending.wait()
                 pending = rt.dist.broadcast(self.xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
-            self.compute(self.xbuf[i & 1])
+            self.compute(self.xbuf[i & 1], i)
 
     def timed(self, steps, warmup):
         rt = self.rt
@@ -348,11 +356,12 @@ class Workload:
                           f"the {len(self.sj_all)} rows at N={self.N}, once: {el:.1f} s"}
 
     def close(self):
-        self.plan.close()
+        for lane in self.lanes:
+            lane[0].close()
 
 
 def measure(rt, config, args, rows_total, opts, want_cpu):
-    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition)
+    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
     out = wl.timed(args.steps, args.warmup)
     out["roofline"] = wl.roofline(args.steps)
     if want_cpu:
@@ -387,6 +396,8 @@ def main():
     ap.add_argument("--shard", default=None, metavar="R/G",
                     help="diagnostic on ONE GPU: compute only the rows rank R of G would own (j = R mod G), with the "
                          "--force-dist broadcast if given; `value` is then what G such ranks would deliver together")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="diagnostic: this many signals in flight (step i on plan / stream / W buffer i mod P); the headline is 1")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
@@ -422,7 +433,8 @@ def main():
                    "tolerance": head["tolerance"],
                    "parallelism": (f"scale-sharded x{world}, 1 broadcast/step, backend {rt.backend}" if world > 1
                                    else "single GPU"),
-                   "plan_options": opts, **({"shard_diagnostic": args.shard} if args.shard else {})},
+                   "plan_options": opts, **({"shard_diagnostic": args.shard} if args.shard else {}),
+                   **({"signals_in_flight": args.pipeline} if args.pipeline > 1 else {})},
         "roofline": head["roofline"],
     }
     for k in ("parity", "cpu_baseline"):

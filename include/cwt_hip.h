@@ -87,8 +87,13 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
  *   "ols_big"      1 = rows with halo >= "ols_big_min_halo" (default 1536) and a block support <= 1/8 tile use blocks
  *                  of two workgroup tiles (default: 1 for precision 32, 0 for 64, where it measured no gain)
+ *   "ols_small_max_halo" overlap-save rows with a halo up to this many samples (multiple of 64, default 512) run on
+ *                  half-size workgroup tiles -- four block transforms in flight per CU instead of two; 0 = none
+ *   "ols_fwd_real" 0 = block spectra of the overlap-save rows from a complex transform of the whole zero-imaginary block
+ *                  instead of the half-length transform of the even/odd-packed block (default 1)
  *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
- *   "ols_tile"     points per workgroup of the overlap-save rows: 8192 (default) or, precision 32 only, 16384
+ *   "ols_tile"     points per workgroup of the overlap-save rows: 8192 (default), 1024 ... 4096 (tuning) or, precision 32
+ *                  only, 16384
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
@@ -142,8 +147,14 @@ int cwt_transform_rows(cwt_plan* plan, const void* xhat_dev, int mother, double 
  * compact in time (filter not clipped at the Nyquist bins, c_H*scale/dt <= a quarter of the workgroup tile) take the
  * overlap-save form: per block of P - 2H output columns one P-point transform of x[n0-H .. n0+P-H) filtered by the same
  * psi_ft sampled on the block's coarser frequency grid -- no N-point inverse transform, no intermediate in memory,
- * contiguous stores.  The neglected tail of the wavelet is below 1e-17 (precision 64) / 5e-7 (32) of its L1 mass.
- * x_dev: n0 reals.  Option "ols" = 0 turns that form off (then exactly the two calls above).                       */
+ * contiguous stores.  The neglected tail of the wavelet is below a tenth of the plan's accuracy target
+ * (cwt_plan_set_tolerance) of its L1 mass.  x_dev: n0 reals.  Option "ols" = 0 turns that form off (then exactly the
+ * two calls above).
+ * NON-FINITE SAMPLES: the reference transforms the whole padded signal, so one NaN / inf sample makes every element of
+ * W NaN (wavelet.py:91).  cwt_forward_fft + cwt_transform_rows reproduce that; cwt_transform does so only for the rows
+ * that go through the spectrum -- its overlap-save rows are NaN only in the output blocks whose input window contains
+ * the sample.  A caller that must match the reference on such input checks the signal (O(n0)) and uses the two-call
+ * path, as the Python shim does (pycwt_amd/wavelet.py:_transform).                                                   */
 /* xhat_dev may be NULL when the caller has no use for the spectrum: it is then computed into plan scratch, and not at
  * all when every row takes the overlap-save form (a rank of a scale-sharded transform that owns only such rows). */
 int cwt_transform(cwt_plan* plan, const void* x_dev, int64_t n0, int mother, double param, double dt,
@@ -264,7 +275,8 @@ int cwt_plan_timings(cwt_plan* plan, int cap, const char** names, double* total_
  * kind 0 = single-workgroup transform, 1 = band-limited single pass (K = 2^logK <= 1024, `terms` aliased bins per
  * input), 2 = band-limited single pass on 16384-point workgroups (K = 2048), 3 = two-pass (logK = log2 of the
  * pass-A column support class, 0 = full column), 4 = overlap-save (K = 2^logK points per aliased block FFT, `terms` =
- * workgroups per block: 1 = blocks of one workgroup tile, 2 = blocks of two).
+ * workgroups per block: 1 = blocks of one workgroup tile, 2 = blocks of two), 5 = overlap-save on half-size workgroup
+ * tiles (short halos; option "ols_small_max_halo").
  * *n = number of rows of the call; codes may be NULL.  The parity
  * tests and bench.py use it to report the worst row per kernel class.                                          */
 int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);

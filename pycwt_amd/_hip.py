@@ -356,6 +356,8 @@ class Plan:
                 out.append(f"narrow_k2048/t{terms}")
             elif kind == 4:
                 out.append(("ols/K" if terms == 1 else f"ols{terms}/K") + str(1 << logk))
+            elif kind == 5:                                  # overlap-save row on half-size workgroup tiles
+                out.append(f"ols/K{1 << logk}/half")
             else:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out

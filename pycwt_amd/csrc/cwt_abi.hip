@@ -42,10 +42,10 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_MANY, KC_NARROW_BIG,
-                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_COUNT };
+                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_OLS_SMALL, KC_COUNT };
 const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a",  "fwd_pass_b", "small",  "direct", "narrow",
                                            "narrow_many", "narrow_big", "pass_a",     "pass_b", "icwt",   "elementwise",
-                                           "ols_fwd", "ols"};
+                                           "ols_fwd", "ols", "ols_small"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -170,6 +170,8 @@ struct cwt_plan {
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_tile = 8192;     // points per workgroup of those rows (fp32: 8192 or 16384)
+  int ols_fwd_real = 1;    // block spectra from a complex transform of half the block length (real-input packing)
+  int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
   int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
   int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
@@ -207,12 +209,19 @@ struct cwt_plan {
     std::vector<Group> narrow_groups;
     int n_small = 0, n_narrow = 0, n_wide = 0, wide_first = 0;
     int n_ols = 0, ols_first = 0;        // overlap-save rows (after the wide rows), sorted by halo class
-    int ols_logp = 13;                   // log2 of their workgroup tile
-    OlsClasses ols_cls;
-    long ols_wgs = 0, ols_xs_elems = 0, ols_gt_elems = 0;
+    // The overlap-save rows run on up to two workgroup-tile sizes: group 0 = half-size tiles (short halos: four tiles
+    // in flight per CU instead of two; measured -10...-20 % per row, profiles/r03_ols_tiles.txt), group 1 = the default tile
+    struct OlsGroup {
+      int logp = 13;                     // log2 of the workgroup tile
+      OlsClasses cls;                    // halo classes of this group (wg_first / row_first relative to the group)
+      long wgs = 0;                      // workgroups of its k_ols_ct launch
+      long fwd_blocks[2] = {0, 0};       // blocks of P points, blocks of 2P points (k_ols_fwd launches)
+      int row_first = 0, nrows = 0;      // its rows inside [ols_first, ols_first + n_ols)
+    };
+    OlsGroup ols_grp[2];
+    long ols_xs_elems = 0, ols_gt_elems = 0;
     void* gt_dev = nullptr;              // filter tables of the overlap-save rows, written when the table is built
     size_t gt_bytes = 0;
-    long ols_fwd_blocks[2] = {0, 0};     // blocks of P points, blocks of 2P points
     RowDesc* rows_dev = nullptr;
     RowDesc* rows_pinned = nullptr;
     hipEvent_t uploaded = nullptr;
@@ -235,7 +244,9 @@ struct cwt_plan {
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
   hipEvent_t ev_ols = nullptr;
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
+  hipStream_t side_hi = nullptr;     // the same at the highest priority (option "sched" bit 1)
   hipEvent_t ev_big = nullptr;
+  int sched = 0;                     // stream placement experiments (bit 0: join side2 directly; bit 1: few-row kernels at high priority)
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
@@ -472,8 +483,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
                       p->logN >= 14;
   // overlap-save rows: default geometry, at least 4 workgroup tiles per row, built-in mothers, one shared spectrum
   // workgroup tile of the overlap-save rows: 8192 points (512 threads); fp32 may also use 16384 (option "ols_tile")
-  const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : 13;
-  p->rt->ols_logp = ols_logp;
+  const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : p->ols_tile == 4096 ? 12 : p->ols_tile == 2048 ? 11 : p->ols_tile == 1024 ? 10 : 13;
+  // half-size tiles for short halos (only beside the default 8192-point tile)
+  const int ols_logp_s = (p->ols_small_max_halo > 0 && ols_logp == 13) ? 12 : 0;
   const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && p->logN >= std::max(p->ols_min_logn, ols_logp + 2) &&
                       mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
   const int ols_P = 1 << ols_logp;
@@ -484,7 +496,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
   double fc_lo = 0, fc_hi = 0;
   if (ols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
-  std::vector<RowDesc> narrow_rows, wide_rows, small_rows, ols_rows;
+  std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
+  struct OlsRow { RowDesc rd; int grp, lb, h64; };
+  std::vector<OlsRow> ols_rows;
   for (int j = 0; j < nrows; ++j) {
     if (!(a[j] > 0) || !std::isfinite(a[j])) return fail(CWT_EINVAL, "scales must be positive and finite");
     RowDesc rd;
@@ -542,7 +556,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       // overlap-save form (see k_ols_ct): halo H = c_H * (scale in samples), a multiple of 64 so that whole
       // wavefronts fall inside or outside the kept part of a block.  Block length P_b = P, or 2P (fp64) where that
       // keeps a larger fraction of every block transform and the stores stay >= 128-byte segments (K <= P/8).
-      int halo = 0, lb = ols_logp;
+      int halo = 0, lb = ols_logp, grp = 1;
       if (ols_ok && unclipped && rd.nband > 0) {
         const double s_samples = rd.a * double(N) / 6.283185307179586476925;
         const double hh = std::ceil(ols_ch * s_samples / 64.0) * 64.0;
@@ -553,7 +567,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         // the same filter sampled on the block's coarser frequency grid: bin k' of a P_b-point block is bin k' N / P_b.
         // K-point block FFTs, K >= the support; the band start is moved down to a multiple of K/16 (the bins added
         // lie below the support threshold) so that the aliased index wraps at the same slot in every thread
-        auto describe = [&](int logb, RowDesc& o) {
+        auto describe = [&](int logb, int logp_tile, RowDesc& o) {
           const int Pb = 1 << logb;
           const double ab = rd.a * double(N >> logb);
           double kl = std::ceil(f_lo / ab), kh = std::floor(f_hi / ab);
@@ -566,7 +580,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           o.k_lo = int(kl);
           o.nband = kh >= kl ? int(kh - kl + 1) : 0;
           if (o.nband == 0) o.k_lo = 0;
-          for (o.logK = std::max(4, ilog2(std::max(o.nband, 1))); o.logK < ols_logp; ++o.logK) {
+          for (o.logK = std::max(4, ilog2(std::max(o.nband, 1))); o.logK < logp_tile; ++o.logK) {
             const int nt = 1 << (o.logK - 4);
             const int lo = o.k_lo - (((o.k_lo % nt) + nt) % nt);
             if (o.nband + (o.k_lo - lo) <= (1 << o.logK) && lo >= -(Pb / 2)) {
@@ -578,22 +592,24 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         };
         RowDesc big = rd;
         bool big_fits = false;
-        if (ols_big && halo >= p->ols_big_min_halo) {
-          describe(ols_logp + 1, big);
-          big_fits = big.logK <= ols_logp - 3;
+        if (ols_logp_s && halo <= p->ols_small_max_halo) {
+          describe(ols_logp_s, ols_logp_s, od);
+          lb = ols_logp_s; grp = 0;
+        } else {
+          if (ols_big && halo >= p->ols_big_min_halo) {
+            describe(ols_logp + 1, ols_logp, big);
+            big_fits = big.logK <= ols_logp - 3;
+          }
+          if (big_fits) { od = big; lb = ols_logp + 1; }
+          else if (halo <= ols_hmax) describe(ols_logp, ols_logp, od);
+          else halo = 0;
         }
-        if (big_fits) { od = big; lb = ols_logp + 1; }
-        else if (halo <= ols_hmax) describe(ols_logp, od);
-        else halo = 0;
       }
       if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
       } else if (halo) {
-        rd = od;
-        rd.tab_off = lb;                                // carried to the class grouping below (unused by these rows)
-        rd.nterms = halo / 64;                          // carried to the class grouping below
-        ols_rows.push_back(rd);
+        ols_rows.push_back({od, grp, lb, halo / 64});
       } else if (k1_ok && (!k2_ok || t1 <= 3)) {
         rd.logK = 10;                                   // k_narrow_ct_all (<= 4 terms) / k_narrow_ct_many
         rd.nterms = t1;
@@ -640,80 +656,90 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // block on top of its rows -> cost (rows + w) * P / (P - 2 H_j); dynamic programme over the distinct halos.
   p->rt->ols_first = int(p->rt->table.size());
   p->rt->n_ols = int(ols_rows.size());
-  p->rt->ols_cls.n = 0;
-  p->rt->ols_wgs = p->rt->ols_xs_elems = p->rt->ols_gt_elems = 0;
-  p->rt->ols_fwd_blocks[0] = p->rt->ols_fwd_blocks[1] = 0;
+  p->rt->ols_xs_elems = p->rt->ols_gt_elems = 0;
+  for (int g = 0; g < 2; ++g) {
+    auto& G = p->rt->ols_grp[g];
+    G.logp = g == 0 ? (ols_logp_s ? ols_logp_s : ols_logp) : ols_logp;
+    G.cls.n = 0; G.wgs = 0; G.fwd_blocks[0] = G.fwd_blocks[1] = 0; G.row_first = G.nrows = 0;
+    for (int i = 0; i < OLS_MAX_CLASSES; ++i) G.cls.wg_first[i] = 0x7fffffff;
+  }
   if (!ols_rows.empty()) {
-    // by block length, then halo
-    std::stable_sort(ols_rows.begin(), ols_rows.end(), [](const RowDesc& x, const RowDesc& y) {
-      return x.tab_off != y.tab_off ? x.tab_off < y.tab_off : x.nterms < y.nterms;
+    // by tile group, then block length, then halo
+    std::stable_sort(ols_rows.begin(), ols_rows.end(), [](const OlsRow& x, const OlsRow& y) {
+      return x.grp != y.grp ? x.grp < y.grp : x.lb != y.lb ? x.lb < y.lb : x.h64 < y.h64;
     });
-    OlsClasses& oc = p->rt->ols_cls;
-    oc.n = 0;
-    long wg = 0, xs = 0;
-    int row0 = 0;
-    for (int lb = ols_logp; lb <= ols_logp + 1; ++lb) {
-      int nr = 0;
-      while (row0 + nr < int(ols_rows.size()) && ols_rows[row0 + nr].tab_off == lb) ++nr;
-      if (!nr) continue;
-      const int Pb = 1 << lb, G = 1 << (lb - ols_logp);
-      std::vector<int> hv, cnt;                                   // distinct halos (units of 64) and their row counts
-      for (int i = row0; i < row0 + nr; ++i) {
-        if (hv.empty() || hv.back() != ols_rows[i].nterms) { hv.push_back(ols_rows[i].nterms); cnt.push_back(0); }
-        cnt.back()++;
+    long xs = 0;
+    int row0 = 0;                                                  // index into ols_rows
+    for (int g = 0; g < 2; ++g) {
+      auto& grp = p->rt->ols_grp[g];
+      OlsClasses& oc = grp.cls;
+      grp.row_first = row0;
+      long wg = 0;
+      for (int lb = grp.logp; lb <= grp.logp + 1; ++lb) {
+        int nr = 0;
+        while (row0 + nr < int(ols_rows.size()) && ols_rows[row0 + nr].grp == g && ols_rows[row0 + nr].lb == lb) ++nr;
+        if (!nr) continue;
+        const int Pb = 1 << lb, G = 1 << (lb - grp.logp);
+        std::vector<int> hv, cnt;                                   // distinct halos (units of 64) and their row counts
+        for (int i = row0; i < row0 + nr; ++i) {
+          if (hv.empty() || hv.back() != ols_rows[i].h64) { hv.push_back(ols_rows[i].h64); cnt.push_back(0); }
+          cnt.back()++;
+        }
+        const int nd = int(hv.size()), KC = OLS_MAX_CLASSES / 2;
+        std::vector<int> pre(nd + 1, 0);
+        for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
+        auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
+          return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(Pb) / double(Pb - 128 * hv[j - 1]);
+        };
+        const double inf = 1e300;
+        std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
+        std::vector<std::vector<int>> from(KC + 1, std::vector<int>(nd + 1, -1));
+        dp[0][0] = 0;
+        for (int k = 1; k <= KC; ++k)
+          for (int j = 1; j <= nd; ++j)
+            for (int i = 0; i < j; ++i)
+              if (dp[k - 1][i] < inf && dp[k - 1][i] + cost(i, j) < dp[k][j]) { dp[k][j] = dp[k - 1][i] + cost(i, j); from[k][j] = i; }
+        int bestk = 1;
+        for (int k = 2; k <= KC; ++k) if (dp[k][nd] < dp[bestk][nd]) bestk = k;
+        std::vector<int> cuts;                                      // class boundaries in distinct-halo indices
+        for (int k = bestk, j = nd; k >= 1; --k) { cuts.push_back(j); j = from[k][j]; }
+        std::reverse(cuts.begin(), cuts.end());
+        int lo_d = 0;
+        long blk = 0;
+        const long stride = (Pb / 2) + 8;
+        for (size_t ci = 0; ci < cuts.size(); ++ci) {
+          const int hi_d = cuts[ci], H = 64 * hv[hi_d - 1], L = Pb - 2 * H;
+          OlsClass& k = oc.c[oc.n++];
+          k.halo = H;
+          k.logb = lb;
+          k.pad_ = 0;
+          k.nblocks = int((ols_ncols + L - 1) / L);
+          k.nrows = pre[hi_d] - pre[lo_d];
+          k.row_first = row0 - grp.row_first + pre[lo_d];
+          k.wg_first = int(wg);
+          k.blk_first = int(blk);
+          k.xs_off = xs;
+          wg += long((k.nblocks + 7) / 8) * 8 * k.nrows * G;
+          blk += k.nblocks;
+          xs += long(k.nblocks) * stride;
+          lo_d = hi_d;
+        }
+        grp.fwd_blocks[lb - grp.logp] = blk;
+        row0 += nr;
       }
-      const int nd = int(hv.size()), KC = OLS_MAX_CLASSES / 2;
-      std::vector<int> pre(nd + 1, 0);
-      for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
-      auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
-        return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(Pb) / double(Pb - 128 * hv[j - 1]);
-      };
-      const double inf = 1e300;
-      std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
-      std::vector<std::vector<int>> from(KC + 1, std::vector<int>(nd + 1, -1));
-      dp[0][0] = 0;
-      for (int k = 1; k <= KC; ++k)
-        for (int j = 1; j <= nd; ++j)
-          for (int i = 0; i < j; ++i)
-            if (dp[k - 1][i] < inf && dp[k - 1][i] + cost(i, j) < dp[k][j]) { dp[k][j] = dp[k - 1][i] + cost(i, j); from[k][j] = i; }
-      int bestk = 1;
-      for (int k = 2; k <= KC; ++k) if (dp[k][nd] < dp[bestk][nd]) bestk = k;
-      std::vector<int> cuts;                                      // class boundaries in distinct-halo indices
-      for (int k = bestk, j = nd; k >= 1; --k) { cuts.push_back(j); j = from[k][j]; }
-      std::reverse(cuts.begin(), cuts.end());
-      int lo_d = 0;
-      long blk = 0;
-      const long stride = (Pb / 2) + 8;
-      for (size_t ci = 0; ci < cuts.size(); ++ci) {
-        const int hi_d = cuts[ci], H = 64 * hv[hi_d - 1], L = Pb - 2 * H;
-        OlsClass& k = oc.c[oc.n++];
-        k.halo = H;
-        k.logb = lb;
-        k.pad_ = 0;
-        k.nblocks = int((ols_ncols + L - 1) / L);
-        k.nrows = pre[hi_d] - pre[lo_d];
-        k.row_first = row0 + pre[lo_d];
-        k.wg_first = int(wg);
-        k.blk_first = int(blk);
-        k.xs_off = xs;
-        wg += long((k.nblocks + 7) / 8) * 8 * k.nrows * G;
-        blk += k.nblocks;
-        xs += long(k.nblocks) * stride;
-        lo_d = hi_d;
-      }
-      p->rt->ols_fwd_blocks[lb - ols_logp] = blk;
-      row0 += nr;
+      grp.nrows = row0 - grp.row_first;
+      grp.wgs = wg;
+      for (int i = 0; i < OLS_MAX_CLASSES; ++i) oc.wg_first[i] = i < oc.n ? oc.c[i].wg_first : 0x7fffffff;
     }
-    for (int i = 0; i < OLS_MAX_CLASSES; ++i) oc.wg_first[i] = i < oc.n ? oc.c[i].wg_first : 0x7fffffff;
     long gt_off = 0;                                            // filter tables: 2^logK entries per row (k_ols_gtab)
     for (auto& r : ols_rows) {
-      r.nterms = 1 << (int(r.tab_off) - ols_logp);               // nterms = workgroups per block
-      r.tab_off = gt_off;
-      gt_off += 1L << r.logK;
+      r.rd.nterms = 1 << (r.lb - p->rt->ols_grp[r.grp].logp);   // nterms = workgroups per block
+      r.rd.tab_off = gt_off;
+      gt_off += 1L << r.rd.logK;
+      p->rt->table.push_back(r.rd);
     }
     p->rt->ols_gt_elems = gt_off;
-    p->rt->ols_wgs = wg; p->rt->ols_xs_elems = xs;
-    p->rt->table.insert(p->rt->table.end(), ols_rows.begin(), ols_rows.end());
+    p->rt->ols_xs_elems = xs;
   }
   return CWT_OK;
 }
@@ -825,7 +851,7 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   // complex64 only: rows with K <= 512 (sorted first) on half-size workgroup tiles (store segments stay
   // >= 128 B): -6 % on this kernel; complex128 measured +7 %
   int n_half = 0;
-  if constexpr (sizeof(T) == 4) {
+  if (sizeof(T) == 4 || p->narrow_small == 2) {
     if (p->narrow_small && p->logN >= LOGP)
       for (const auto& g : p->rt->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
     for (int r0 = 0; r0 < n_half; r0 += kMaxGridY)
@@ -1061,48 +1087,98 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
 
 // Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd) ...
 template <typename T, int LOGM, int LOGD>
-int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, hipStream_t st) {
+int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
   static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGM, LOGD>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
   return timed_launch(p, KC_OLS_FWD, [&] {
     hipLaunchKernelGGL((k_ols_fwd<T, LOGM, LOGD>), dim3(unsigned(blocks << LOGD)), dim3(1 << (LOGM - 4)), lds, st,
-                       static_cast<const T*>(x_dev), long(n0), p->logN, p->rt->ols_cls,
+                       static_cast<const T*>(x_dev), long(n0), p->logN, cls,
                        static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
+  }, st);
+}
+// ... from a complex transform of half the block length (k_ols_fwd_r; block length 2^(LOGM + 1))
+template <typename T, int LOGM>
+int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
+  const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
+  return timed_launch(p, KC_OLS_FWD, [&] {
+    hipLaunchKernelGGL((k_ols_fwd_r<T, LOGM>), dim3(unsigned(blocks)), dim3(1 << (LOGM - 4)), lds, st,
+                       static_cast<const T*>(x_dev), long(n0), p->logN, cls, static_cast<const cplx<T>*>(p->tw_all),
+                       static_cast<cplx<T>*>(p->xs));
   }, st);
 }
 template <typename T>
 int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
-  const long* nb = p->rt->ols_fwd_blocks;
   int rc = CWT_OK;
-  if (p->rt->ols_logp == 13) {
-    if (nb[0]) rc = launch_ols_fwd_b<T, 13, 0>(p, x_dev, n0, nb[0], st);
-    if (!rc && nb[1]) rc = launch_ols_fwd_b<T, 13, 1>(p, x_dev, n0, nb[1], st);   // double-length blocks, two tiles each
-  } else if constexpr (sizeof(T) == 4) {
-    if (nb[0]) rc = launch_ols_fwd_b<T, 14, 0>(p, x_dev, n0, nb[0], st);
+  if (p->ols_fwd_real) {
+    for (int g = 0; g < 2 && !rc; ++g) {
+      const auto& G = p->rt->ols_grp[g];
+      if (!G.nrows) continue;
+      for (int d = 0; d < 2 && !rc; ++d) {
+        if (!G.fwd_blocks[d]) continue;
+        switch (G.logp + d) {                                   // log2 of the block length
+          case 10: rc = launch_ols_fwd_r<T, 9>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          case 11: rc = launch_ols_fwd_r<T, 10>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          case 12: rc = launch_ols_fwd_r<T, 11>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          case 13: rc = launch_ols_fwd_r<T, 12>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          case 14: rc = launch_ols_fwd_r<T, 13>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          default: return fail(CWT_EINVAL, "overlap-save block length");
+        }
+      }
+    }
+    return rc;
+  }
+  for (int g = 0; g < 2 && !rc; ++g) {
+    const auto& G = p->rt->ols_grp[g];
+    const long* nb = G.fwd_blocks;
+    if (!G.nrows) continue;
+    switch (G.logp) {
+      case 10: if (nb[0]) rc = launch_ols_fwd_b<T, 10, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
+      case 11: if (nb[0]) rc = launch_ols_fwd_b<T, 11, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
+      case 12: if (nb[0]) rc = launch_ols_fwd_b<T, 12, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
+      case 13:
+        if (nb[0]) rc = launch_ols_fwd_b<T, 13, 0>(p, x_dev, n0, nb[0], G.cls, st);
+        if (!rc && nb[1]) rc = launch_ols_fwd_b<T, 13, 1>(p, x_dev, n0, nb[1], G.cls, st);   // double-length blocks, two tiles each
+        break;
+      case 14:
+        if constexpr (sizeof(T) == 4) { if (nb[0]) rc = launch_ols_fwd_b<T, 14, 0>(p, x_dev, n0, nb[0], G.cls, st); }
+        break;
+      default: return fail(CWT_EINVAL, "overlap-save tile size");
+    }
   }
   return rc;
 }
 // ... and the rows themselves (k_ols_ct)
 template <typename T, int LOGP>
-int launch_ols_rows_p(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
+  const auto& G = rt->ols_grp[g];
   static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-  return timed_launch(p, KC_OLS, [&] {
-    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(rt->ols_wgs)), dim3(1 << (LOGP - 4)), lds, st,
-                       static_cast<const cplx<T>*>(p->xs), rt->rows_dev + rt->ols_first,
+  return timed_launch(p, g == 0 ? KC_OLS_SMALL : KC_OLS, [&] {
+    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(G.wgs)), dim3(1 << (LOGP - 4)), lds, st,
+                       static_cast<const cplx<T>*>(p->xs), rt->rows_dev + rt->ols_first + G.row_first,
                        static_cast<const cplx<T>*>(rt->gt_dev), static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
-                       p->logN, rt->ols_cls, W, long(ldw), long(ncols));
+                       p->logN, G.cls, W, long(ldw), long(ncols));
   }, st);
 }
 template <typename T>
 int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
-  if constexpr (sizeof(T) == 4) {
-    if (p->rt->ols_logp == 14) return launch_ols_rows_p<T, 14>(p, W, ldw, ncols, st);
+  int rc = CWT_OK;
+  for (int g = 1; g >= 0 && !rc; --g) {       // the default tile's rows first (the longer launch), then the half-size tiles
+    const auto& G = p->rt->ols_grp[g];
+    if (!G.nrows) continue;
+    switch (G.logp) {
+      case 10: rc = launch_ols_rows_p<T, 10>(p, g, W, ldw, ncols, st); break;
+      case 11: rc = launch_ols_rows_p<T, 11>(p, g, W, ldw, ncols, st); break;
+      case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
+      case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
+      case 14: if constexpr (sizeof(T) == 4) rc = launch_ols_rows_p<T, 14>(p, g, W, ldw, ncols, st); break;
+      default: return fail(CWT_EINVAL, "overlap-save tile size");
+    }
   }
-  return launch_ols_rows_p<T, 13>(p, W, ldw, ncols, st);
+  return rc;
 }
 
 template <typename T>
@@ -1226,17 +1302,19 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
       // the multi-term kernels (few rows, long workgroups) on a stream of their own: at small row counts (a rank's
       // share of 8) they would otherwise run alone at the end of the step
       const bool big_on_side2 = narrow_on_side && n_small_k && (n_many || n_big);
+      hipStream_t sbig = (p->sched & 2) ? p->side_hi : p->side2;
       if (big_on_side2) {
-        HIPCHECK(hipStreamWaitEvent(p->side2, p->ev_fork, 0));
-        p->stream = p->side2;
+        HIPCHECK(hipStreamWaitEvent(sbig, p->ev_fork, 0));
+        p->stream = sbig;
       }
       if (!rc && n_many) rc = timed_launch(p, KC_NARROW_MANY, [&] { launch_narrow_ct_many<T>(p, xhat, mo, W, ldw, ncols); });
       if (!rc && n_big) rc = timed_launch(p, KC_NARROW_BIG, [&] { launch_narrow_ct_big<T>(p, xhat, mo, W, ldw, ncols); });
       p->stream = keep;
       if (rc) return rc;
       if (big_on_side2) {
-        HIPCHECK(hipEventRecord(p->ev_big, p->side2));
-        HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_big, 0));          // joined through side stream 0
+        HIPCHECK(hipEventRecord(p->ev_big, sbig));
+        if (p->sched & 1) HIPCHECK(hipStreamWaitEvent(keep, p->ev_big, 0));   // joined directly
+        else HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_big, 0));          // joined through side stream 0
       }
       if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
     } else {
@@ -1402,6 +1480,12 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
+  if (!rc) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&p->side_hi, hipStreamNonBlocking, greatest) != hipSuccess)
+      rc = fail(CWT_EHIP, "cannot create side streams/events");
+  }
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
     if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
@@ -1434,6 +1518,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
+  if (p->side_hi) { (void)hipStreamSynchronize(p->side_hi); (void)hipStreamDestroy(p->side_hi); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1486,7 +1571,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_big") p->narrow_big = value != 0;
   else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
-  else if (k == "narrow_small") p->narrow_small = value != 0;
+  else if (k == "narrow_small") p->narrow_small = int(value);
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "pass_b_small") p->pass_b_small = value != 0;
   else if (k == "pass_b_prefetch") { if (value != 0 && value != 2 && value != 4) return fail(CWT_EINVAL, "pass_b_prefetch: 0, 2 or 4 tiles"); p->pass_b_prefetch = int(value); }
@@ -1504,11 +1589,14 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
     }
   }
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
+  else if (k == "sched") p->sched = int(value);
   else if (k == "ols") p->ols = value != 0;
   else if (k == "ols_side") p->ols_side = value != 0;
   else if (k == "ols_big") p->ols_big = value != 0;
   else if (k == "ols_min_logn") { if (value < 15 || value > 24) return fail(CWT_EINVAL, "ols_min_logn in [15, 24]"); p->ols_min_logn = int(value); }
-  else if (k == "ols_tile") { if (value != 8192 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
+  else if (k == "ols_tile") { if (value != 8192 && value != 4096 && value != 2048 && value != 1024 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 1024, 2048, 4096, 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
+  else if (k == "ols_fwd_real") p->ols_fwd_real = value != 0;
+  else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
@@ -1628,14 +1716,18 @@ int fill_ols_tables(cwt_plan* p, const Mother& mo) {
   cwt_plan::RowTable* t = p->rt;
   int rc = grow(&t->gt_dev, &t->gt_bytes, size_t(t->ols_gt_elems) * sizeof(cplx<T>), p->stream);
   if (rc) return rc;
-  int maxk = 16;
-  for (int i = 0; i < t->n_ols; ++i) maxk = std::max(maxk, 1 << t->table[t->ols_first + i].logK);
-  const dim3 grid((maxk + 255) / 256, t->n_ols), block(256);
   cplx<T>* gt = static_cast<cplx<T>*>(t->gt_dev);
-  const RowDesc* rows = t->rows_dev + t->ols_first;
-  if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
-  else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
-  else hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, t->ols_logp, gt);
+  for (int g = 0; g < 2; ++g) {             // one launch per tile size: a row's K = P table is indexed by signed bins
+    const auto& G = t->ols_grp[g];
+    if (!G.nrows) continue;
+    int maxk = 16;
+    for (int i = 0; i < G.nrows; ++i) maxk = std::max(maxk, 1 << t->table[t->ols_first + G.row_first + i].logK);
+    const dim3 grid((maxk + 255) / 256, G.nrows), block(256);
+    const RowDesc* rows = t->rows_dev + t->ols_first + G.row_first;
+    if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, G.logp, gt);
+    else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, G.logp, gt);
+    else hipLaunchKernelGGL((k_ols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, G.logp, gt);
+  }
   HIPCHECK(hipGetLastError());
   return CWT_OK;
 }
@@ -2201,7 +2293,10 @@ int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
   if (!codes) return CWT_OK;
   for (int i = 0; i < total; ++i) {
     const RowDesc& rd = p->rt->table[i];
-    const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : i < p->rt->ols_first ? 3 : 4;
+    // 0 single-workgroup, 1 band-limited, 2 band-limited K = 2048, 3 two-pass, 4 overlap-save, 5 overlap-save on half-size tiles
+    const int small_end = p->rt->ols_first + (p->rt->ols_grp[0].logp != p->rt->ols_grp[1].logp ? p->rt->ols_grp[0].nrows : 0);
+    const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : i < p->rt->ols_first ? 3 :
+                     i < small_end ? 5 : 4;
     if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
   }
   return CWT_OK;

@@ -85,6 +85,9 @@ struct TwN {
   const cplx<T>* lo;  // lo[i] = e^{2 pi i i / N}, i < (1 << shift)
   int shift;
   __device__ __forceinline__ cplx<T> operator()(unsigned t) const {
+#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
+    return mk<T>(T(1) - T(t) * T(1e-9), T(t) * T(1e-9));   // timing only: no table look-ups
+#endif
     return cmul<T>(hi[t >> shift], lo[t & ((1u << shift) - 1u)]);
   }
 };
@@ -526,7 +529,11 @@ __device__ __forceinline__ void narrow_phases(const cplx<T>* __restrict__ xhat, 
   for (int idx = threadIdx.x; idx < NTERMS * KQ; idx += (1 << (LOGP - 4))) {
     const int i = idx / KQ, q = PH * KQ + (idx - i * KQ);
     const int dq = (q - rd.k_lo) & (K - 1);
+#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
+    ytile[idx] = mk<T>(T(dq) * T(1e-3), T(i));             // timing only: no spectrum loads, no filter evaluation
+#else
     ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + dq + (i << LOGK), N - 1);
+#endif
   }
   __syncthreads();
 #pragma unroll
@@ -1075,6 +1082,69 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
   if (f.j == 0 && part == 0) out[PB / 2] = mk<T>(re[8], -im[8]);
 }
 
+// The same half spectra from a complex transform of HALF the block length (the classic real-input packing): with
+// z[n] = x[2n] + i x[2n+1], n < M = P_b / 2, and Z = FFT_M(z),
+//   X_b[k] = E[k] + e^{-2 pi i k / P_b} O[k],  E[k] = (Z[k] + conj Z[M-k]) / 2,  O[k] = (Z[k] - conj Z[M-k]) / (2i),  k <= M
+// (Z[M] = Z[0]).  One workgroup of M/16 threads per block: half the butterflies and half the registers / LDS of the
+// complex transform of the zero-imaginary block, twice the workgroups in flight per CU; the mirrored operand Z[M-k] comes
+// through one extra pass of the exchange buffer.  Blocks of two workgroup tiles (P_b = 2P) are ONE M = P transform.
+template <typename T, int LOGM>
+__global__ void __launch_bounds__(1 << (LOGM - 4), 4)
+k_ols_fwd_r(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all,
+            cplx<T>* __restrict__ xs) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int M = 1 << LOGM, NT = M >> 4, LOGB = LOGM + 1, PB = 1 << LOGB;
+  using F = ct::Fft<T, LOGM, 0, false>;
+  const int wg = int(blockIdx.x);
+  int c = 0;
+  for (int i = 0; i < cls.n; ++i)
+    if (cls.c[i].logb == LOGB && wg >= cls.c[i].blk_first) c = i;
+  const int blk = wg - cls.c[c].blk_first, H = cls.c[c].halo, L = PB - 2 * H;
+  const long nmask = (1L << logN) - 1;
+  const long first = long(blk) * L - H;                    // even: L and H are multiples of 64
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  T re[16], im[16];
+  // forward = conj(inverse(conj z)): feed (x[2n], -x[2n+1])
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long n = (first + 2 * (f.j + e * NT)) & nmask;   // even, so n + 1 does not wrap
+    re[e] = n < n0 ? x[n] : T(0);
+    im[e] = n + 1 < n0 ? -x[n + 1] : T(0);
+  }
+  f.run(re, im, lds, tw_all + (M - 2));
+  // slot e holds conj(Z[k]), k = j + e NT.  Mirror pass: slot e <- the same plane at position (M - k) mod M
+  T mr[16], mi[16];
+  const int self = f.phys(f.j);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lds[self + e * F::pstride(NT)] = re[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mr[e] = lds[f.phys((M - f.j - e * NT) & (M - 1))];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lds[self + e * F::pstride(NT)] = im[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mi[e] = lds[f.phys((M - f.j - e * NT) & (M - 1))];
+  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ((PB >> 1) + 8);
+  const cplx<T>* twb = tw_all + (PB - 2);                  // e^{2 pi i p / P_b}
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = f.j + e * NT;
+    // Z[k] = (re, -im), conj Z[M-k] = (mr, +mi)
+    const T er = T(0.5) * (re[e] + mr[e]), ei = T(0.5) * (mi[e] - im[e]);          // E = (Z + conj Zm) / 2
+    const T dr = T(0.5) * (re[e] - mr[e]), di = T(0.5) * (-im[e] - mi[e]);         // D = (Z - conj Zm) / 2,  O = D / i = (di, -dr)
+    const cplx<T> w = twb[k];                                                      // e^{+2 pi i k / P_b}; we need its conjugate
+    const T orr = di, oi = -dr;
+    out[k] = mk<T>(er + orr * w.x + oi * w.y, ei + oi * w.x - orr * w.y);          // E + conj(w) O
+    if (k == 0) out[M] = mk<T>(er - orr, T(0));                                    // X[M] = Re Z[0] - Im Z[0]
+  }
+}
+
 // Block transform with K = P: every thread filters its own 16 bins (rows whose block support exceeds P/2 bins).
 template <typename T, int LOGP>
 __device__ __forceinline__ void ols_full_body(const cplx<T>* __restrict__ xb, const RowDesc& rd,
@@ -1127,8 +1197,12 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
   for (int i = 0; i < NQ; ++i) {
     const int q = int(threadIdx.x) + i * BD;
     if (q < K) {
+#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
+      yv[i] = mk<T>(T(q) * T(1e-3), T(1)); gv[i] = mk<T>(T(1), T(q) * T(1e-4));   // timing only: no band / table loads
+#else
       yv[i] = ols_load<T>(xb, rd, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
       gv[i] = gt[q];
+#endif
     }
   }
 #pragma unroll

@@ -29,6 +29,21 @@ _plans_lock = threading.Lock()
 PLAN_OPTIONS: dict = {}
 
 
+def set_tolerance(rel_tol=None):
+    """Accuracy target of every transform of this module from now on: the bound, per row of W, on
+    max|W - W_reference| / max|W_reference| that the engine's fast forms may spend (`cwt_plan_set_tolerance`).
+    None / 0 = the engine's default (1e-9 for complex128, 3e-5 for complex64: measured worst-row errors 2e-10 / 5e-6
+    at N = 2^20); 1e-16 = every truncation below fp64 rounding."""
+    with _plans_lock:
+        if rel_tol:
+            PLAN_OPTIONS["tolerance"] = float(rel_tol)
+        else:
+            PLAN_OPTIONS.pop("tolerance", None)
+        for plan in _plans.values():
+            if plan.h:
+                plan.set_tolerance(float(rel_tol or 0.0))
+
+
 def _check_parameter_wavelet(wavelet):
     """wavelet.py:650-663: lower-case name -> default instance (KeyError if unknown); objects pass."""
     if isinstance(wavelet, str):
@@ -65,6 +80,39 @@ def _reduction_plan(precision: int, device: int, rows: int) -> _hip.Plan:
             if prec == precision and dev == device and plan.max_rows >= rows and plan.h:
                 return plan
     return _plan(16, precision, device, rows)
+
+
+def _transform(plan, x_host, xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr):
+    """Signal (already uploaded at xd_ptr) -> spectrum and rows of W on the device.
+
+    `cwt_transform` computes time-compact rows block by block from the signal itself (overlap-save), so a NaN or inf
+    sample would only poison the blocks that contain it.  The reference transforms the whole padded signal
+    (wavelet.py:91): one non-finite sample makes EVERY bin of the spectrum, hence every element of W, NaN.  To stay a
+    drop-in, such signals go through the spectrum-only entry points (`cwt_forward_fft` + `cwt_transform_rows`, which
+    never use the overlap-save form); the O(N) host scan is free next to the PCIe transfer of W."""
+    if np.isfinite(x_host).all():
+        plan.transform(xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr, n0, n0)
+    else:
+        plan.forward_fft(xd_ptr, n0, xh_ptr)
+        plan.transform_rows(xh_ptr, kind, param, dt, sj, W_ptr, n0, n0)
+
+
+def _cwt_builtin(x, dt, sj, kind, param, N, precision, device):
+    """W (rows x n0) and the spectrum (N) for a built-in mother through the device-resident entry points."""
+    plan = _plan(N, precision, device, sj.size)
+    if np.isfinite(x).all():
+        return plan.execute_host(x, kind, param, dt, sj)
+    es = np.dtype(plan.real).itemsize
+    n0 = x.size
+    sc = _Scratch(device)
+    try:
+        xd, xh, Wd = sc.new(n0 * es), sc.new(N * 2 * es), sc.new(sj.size * n0 * 2 * es)
+        with plan.lock:
+            xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
+            _transform(plan, x, xd.ptr, n0, kind, param, dt, sj, xh.ptr, Wd.ptr)
+            return Wd.download(plan, (sj.size, n0), plan.cplx), xh.download(plan, (N,), plan.cplx)
+    finally:
+        sc.free()
 
 
 def _device_id(mother, strict=True):
@@ -198,14 +246,16 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
         kind, param = _device_id(mother)
         W, xhat = _cwt_unpadded(np.ascontiguousarray(signal, dtype=real), dt, sj, kind, param, precision, device)
     elif hasattr(mother, "device_id"):
+        x = np.asarray(signal, dtype=real)
         bad = _nan_rows(mother, sj, N, dt)
-        if bad.any() and not bad.all():                     # wavelet.py:111-115
+        # wavelet.py:111-115 drops the rows that are NaN throughout -- unless EVERY row is, which is what a NaN / inf
+        # sample does to the whole matrix (:91): then the reference keeps all rows, and so do we
+        if bad.any() and not bad.all() and np.isfinite(x).all():
             keep = ~bad
             sj = sj[keep]
             freqs = np.asarray(freqs)[keep]
         kind, param = mother.device_id()
-        plan = _plan(N, precision, device, sj.size)
-        W, xhat = plan.execute_host(np.asarray(signal, dtype=real), kind, param, dt, sj)
+        W, xhat = _cwt_builtin(x, dt, sj, kind, param, N, precision, device)
     else:
         W, xhat, keep = _cwt_with_host_filter_bank(np.asarray(signal, dtype=real), dt, sj, mother, N, precision,
                                                    device)
@@ -285,7 +335,7 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
     N = _next_pow2(n0)
     bad = _nan_rows(mother, sj, N, dt)
-    if bad.any() and not bad.all():
+    if bad.any() and not bad.all() and np.isfinite(np.asarray(signal, dtype=np.float64)).all():   # see cwt()
         sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
     kind, param = _device_id(mother)
     plan = _plan(N, precision, device, sj.size)
@@ -294,8 +344,9 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     Wd = _hip.DeviceBuffer(sj.size * n0 * 2 * es, device)
     try:
         with plan.lock:
-            xd.upload(plan, np.ascontiguousarray(signal, dtype=plan.real))
-            plan.transform(xd.ptr, n0, kind, param, dt, sj, xh.ptr, Wd.ptr, n0, n0)
+            xs_host = np.ascontiguousarray(signal, dtype=plan.real)
+            xd.upload(plan, xs_host)
+            _transform(plan, xs_host, xd.ptr, n0, kind, param, dt, sj, xh.ptr, Wd.ptr)
             xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
     except Exception:
         Wd.free()
@@ -538,8 +589,9 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
             xd, xh = alloc(n0 * es), alloc(N * 2 * es)
             W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
             for x, W in ((x1, W1), (x2, W2)):
-                xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
-                plan.transform(xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, n0, n0)
+                xh_ = np.ascontiguousarray(x, dtype=plan.real)
+                xd.upload(plan, xh_)
+                _transform(plan, xh_, xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr)
             P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
             plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
             spec = alloc(rows * N * 2 * es)

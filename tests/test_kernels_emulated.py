@@ -360,6 +360,8 @@ def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
     (orc.MORLET, 6, 64, {"ols_big": 0}),
     (orc.DOG, 2, 32, {"ols_tile": 16384}),                 # fp32 on 16384-point tiles (no double-length blocks)
     (orc.PAUL, 4, 32, {"ols_big_min_halo": 512}),
+    (orc.MORLET, 6, 64, {"ols_tile": 4096}),               # quarter-CU tiles (256 threads)
+    (orc.DOG, 2, 32, {"ols_tile": 4096}),
 ])
 def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opts):
     N = 1 << 17
@@ -371,6 +373,8 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
     split, classes = plan.last_split(), plan.row_classes()
     plan.close()
     assert split["ols"] >= 6, split
+    if opts == {"ols_big": 0}:     # default tiles: short halos on half-size tiles, the rest on the default tile, in ONE transform
+        assert any(c.endswith("/half") for c in classes) and any(c.startswith("ols/") and not c.endswith("/half") for c in classes)
     big = [c for c in classes if c.startswith("ols2/")]
     assert bool(big) == (opts.get("ols_big", int(prec == 32)) == 1 and opts.get("ols_tile", 8192) == 8192), sorted(set(classes))
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])

@@ -285,3 +285,29 @@ def test_drop_in_call_with_overlap_save_rows(emulated, monkeypatch, name, dt, n0
     W2 = pycwt_amd.cwt(x, dt, wavelet=name, freqs=1 / (mother.flambda() * sel))[0]
     per_row, _ = row_errors(W2, ref[3:40:4])
     assert per_row.max() < 1e-12
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("name", ["morlet", "paul"])
+def test_non_finite_sample_poisons_every_row_like_the_reference(emulated, monkeypatch, bad, name):
+    """wavelet.py:91 transforms the whole padded signal, so ONE NaN / inf sample makes every bin of the spectrum and
+    every element of W NaN, and :111-115 then keeps all rows (also the ones Paul would lose otherwise).  The
+    overlap-save rows would confine the damage to the blocks that contain the sample; the shim routes such signals
+    through the spectrum-only entry points instead."""
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "PLAN_OPTIONS", {"ols_min_logn": 15})
+    n0 = 40000
+    x = np.random.default_rng(3).standard_normal(n0)
+    good = pycwt_amd.cwt(x, 1.0, 1 / 4, -1, -1, name)
+    plan = next(iter(wavelet._plans.values()))
+    if name == "morlet":
+        assert plan.last_split()["ols"] >= 4                # the clean signal does use the overlap-save rows
+    x[12345] = bad
+    W, sj, freqs, coi, fft, fftfreqs = pycwt_amd.cwt(x, 1.0, 1 / 4, -1, -1, name)
+    ref = orc.cwt(x, 1.0, 1 / 4, -1, -1, name)
+    assert W.shape == ref[0].shape and W.shape[0] >= good[0].shape[0]
+    assert np.isnan(W).all() and np.isnan(ref[0]).all()
+    np.testing.assert_allclose(sj, ref[1], rtol=1e-15)
+    assert not np.isfinite(fft).any()
+    T = pycwt_amd.cwt_device(x, 1.0, 1 / 4, -1, -1, name)
+    assert np.isnan(T.W()).all() and T.shape == W.shape

@@ -71,3 +71,24 @@ def test_cwt_and_icwt_match_reference_call_for_call(emulated, call):
         iw = pycwt_amd.icwt(W, out[1], dt, dj, name)
         assert iw.dtype == iw_ref.dtype
         np.testing.assert_allclose(iw, iw_ref, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(iw_ref).max()))
+
+
+@pytest.mark.parametrize("name", ["morlet", "paul", "dog"])
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_non_finite_sample_against_the_live_reference(emulated, monkeypatch, name, bad):
+    """One NaN / inf sample: the unmodified reference returns an all-NaN W with every row kept (wavelet.py:91, :111-115);
+    so does the shim, also at a length where clean signals use the overlap-save rows."""
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "PLAN_OPTIONS", {"ols_min_logn": 15})
+    ref = _ref()
+    x = np.random.default_rng(5).standard_normal(33000)
+    x[777] = bad
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out_ref = ref.cwt(x, 0.5, 0.5, -1, -1, name)
+    out = pycwt_amd.cwt(x, 0.5, 0.5, -1, -1, name)
+    assert out[0].shape == out_ref[0].shape
+    assert np.isnan(out_ref[0]).all() and np.isnan(out[0]).all()
+    for a, b in zip(out[1:4], out_ref[1:4]):
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+    assert not np.isfinite(out[4]).any() and not np.isfinite(out_ref[4]).any()
