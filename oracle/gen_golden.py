@@ -16,6 +16,8 @@ Cases:
   callers        significance / xwt / Morlet.smooth / wct (deterministic part)
   mc_significance  wct_significance with np.random.seed (two small cases) + rednoise seed for seed
   unpadded       the pyfftw branch (transform length = len(signal), helpers.py:15-19) at n0 = 504, 1000, 331
+  sample_<name>  the sample/sample.py recipe on the reference's other datasets (sample/dataset.py:68-135): mauna,
+                 monsoon, sunspot, soi -- anomaly / std, default s0 and J, Morlet(6); every third row of W is kept
 The signal itself is stored too (NINO3 data is 504 floats).
 """
 import os
@@ -62,6 +64,19 @@ def nino3():
     iW = ref.icwt(W, sj, dt, 1 / 12, "morlet")
     save("nino3_default", x=x2, dt=dt, dj=1 / 12, W=W, sj=sj, freqs=freqs, coi=coi,
          fft=fft, fftfreqs=fftfreqs, icwt=iW)
+
+
+def datasets():
+    """sample/sample.py:41-72 on the datasets of sample/dataset.py other than NINO3 (different lengths and sampling
+    steps: 456 x 1/12, 496 x 1/4, 992 x 1/4, 399 x 1/4)."""
+    for name, dt in (("mauna", 0.08333333), ("monsoon", 0.25), ("sunspot", 0.25), ("soi", 0.25)):
+        dat = np.loadtxt("/root/reference/pycwt/sample/%s.dat" % name)
+        x = (dat - dat.mean()) / dat.std()
+        m = ref.Morlet(6)
+        W, sj, freqs, coi, fft, fftfreqs = ref.cwt(x, dt, 1 / 12, -1, -1, m)
+        iW = ref.icwt(W, sj, dt, 1 / 12, m)
+        save("sample_" + name, x=x, dt=dt, dj=1 / 12, rows=np.arange(0, W.shape[0], 3), W=W[::3], nrows=W.shape[0],
+             sj=sj, freqs=freqs, coi=coi, fft=fft, fftfreqs=fftfreqs, icwt=iW)
 
 
 def small():
@@ -205,11 +220,15 @@ if __name__ == "__main__":
     if "--unpadded-only" in sys.argv:
         unpadded()
         sys.exit(0)
+    if "--datasets-only" in sys.argv:
+        datasets()
+        sys.exit(0)
     callers()
     sys.exit(0) if "--callers-only" in sys.argv else None
     mc_significance()
     unpadded()
     nino3()
+    datasets()
     small()
     mid()
     big()

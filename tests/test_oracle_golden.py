@@ -147,3 +147,21 @@ def test_unpadded_branch_of_the_reference():
         assert out[0].shape == g[f"{tag}_W"].shape and per_row.max() < 1e-12 and l2 < 1e-12
         for got, key in zip(out[1:], ("sj", "freqs", "coi", "fft", "fftfreqs")):
             np.testing.assert_allclose(got, g[f"{tag}_{key}"], rtol=1e-12, atol=1e-13)
+
+
+SAMPLES = ["mauna", "monsoon", "sunspot", "soi"]
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_reference_sample_datasets(name):
+    """sample/sample.py's recipe on the reference's other datasets (sample/dataset.py:68-135; fixtures hold every third
+    row of W): lengths 456 / 496 / 992 / 400, dt = 1/12 and 1/4."""
+    g = load_golden("sample_" + name)
+    W, sj, freqs, coi, fft, fftfreqs = orc.cwt(g["x"], float(g["dt"]), 1 / 12, -1, -1, orc.Mother(orc.MORLET, 6))
+    assert W.shape == (int(g["nrows"]), g["x"].size)
+    per_row, l2 = row_errors(W[g["rows"]], g["W"])
+    assert per_row.max() < TOL and l2 < TOL
+    for a, b in ((sj, g["sj"]), (freqs, g["freqs"]), (coi, g["coi"]), (fftfreqs, g["fftfreqs"])):
+        np.testing.assert_allclose(a, b, rtol=1e-14)
+    np.testing.assert_allclose(fft, g["fft"], rtol=0, atol=1e-13 * np.abs(g["fft"]).max())
+    np.testing.assert_allclose(orc.icwt(W, sj, float(g["dt"]), 1 / 12, orc.Mother(orc.MORLET, 6)), g["icwt"], rtol=1e-12, atol=1e-13)

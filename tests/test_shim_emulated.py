@@ -311,3 +311,18 @@ def test_non_finite_sample_poisons_every_row_like_the_reference(emulated, monkey
     assert not np.isfinite(fft).any()
     T = pycwt_amd.cwt_device(x, 1.0, 1 / 4, -1, -1, name)
     assert np.isnan(T.W()).all() and T.shape == W.shape
+
+
+@pytest.mark.parametrize("name", ["mauna", "monsoon", "sunspot", "soi"])
+def test_reference_sample_datasets_through_the_shim(emulated, name):
+    """The reference's other sample datasets (sample/dataset.py:68-135) with sample/sample.py's recipe, fixtures from
+    the unmodified reference (every third row of W kept)."""
+    g = load_golden("sample_" + name)
+    W, sj, freqs, coi, fft, fftfreqs = pycwt_amd.cwt(g["x"], float(g["dt"]), 1 / 12, -1, -1, pycwt_amd.Morlet(6))
+    assert W.shape == (int(g["nrows"]), g["x"].size) and W.dtype == np.complex128
+    per_row, l2 = row_errors(W[g["rows"]], g["W"])
+    assert per_row.max() < 1e-12 and l2 < 1e-12
+    for a, b in ((sj, g["sj"]), (freqs, g["freqs"]), (coi, g["coi"]), (fftfreqs, g["fftfreqs"])):
+        np.testing.assert_allclose(a, b, rtol=1e-14)
+    np.testing.assert_allclose(fft, g["fft"], rtol=0, atol=1e-12 * np.abs(g["fft"]).max())
+    np.testing.assert_allclose(pycwt_amd.icwt(W, sj, float(g["dt"]), 1 / 12, pycwt_amd.Morlet(6)), g["icwt"], rtol=1e-10, atol=1e-11)
