@@ -62,7 +62,9 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision /* 
 int cwt_plan_destroy(cwt_plan* plan);
 /* hipStream_t handle (as void*) all later launches of this plan are queued on. */
 int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
-/* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  Keys:
+/* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  Keys marked [lab] select measured-and-rejected kernel variants
+ * or diagnostics that exist only in -DCWT_LAB builds of the library (tools/build_variants.py; DESIGN.md's experiment
+ * tables); the product library refuses them.  Keys:
  *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex); 0 = default:
  *                  as many rows as fit 192 MiB, so that the intermediate stays in the Infinity Cache
  *   "narrow"       0 disables the band-limited single-pass path
@@ -71,7 +73,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "wg_points"    complex points per workgroup of the fused kernels
  *   "narrow_terms" largest number of aliased bins per FFT input of that path at K = 1024 (1 = off, <= 16)
  *   "big_terms"    the same at K = 2048 (fp64, 16384-point workgroups; <= 8)
- *   "overlap"      1 = run pass A of chunk c+1 beside pass B of chunk c on side
+ *   "overlap"      [lab] 1 = run pass A of chunk c+1 beside pass B of chunk c on side
  *                  streams; 0 (default) = strictly one after the other
  *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
  *   "overlap_narrow" 1 (default) = queue the band-limited rows on a side stream beside the two-pass chain
@@ -80,8 +82,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "pass_a_small" 0 = pass A on full-size workgroup tiles (default 1: half-size tiles, 4 per CU)
  *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size)
  *   "two_pass_logk" log2 of the row length K of the two-pass split N = R*K (0 = default: 1024 up to 2^21, 2048 above)
- *   "pass_b_small" 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
- *   "stamps"       n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
+ *   "pass_b_small" [lab] 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
+ *   "stamps"       [lab] n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
  *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
@@ -89,10 +91,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  of two workgroup tiles (default: 1 for precision 32, 0 for 64, where it measured no gain)
  *   "ols_small_max_halo" overlap-save rows with a halo up to this many samples (multiple of 64, default 512) run on
  *                  half-size workgroup tiles -- four block transforms in flight per CU instead of two; 0 = none
- *   "ols_fwd_real" 0 = block spectra of the overlap-save rows from a complex transform of the whole zero-imaginary block
+ *   "ols_fwd_real" [lab] 0 = block spectra of the overlap-save rows from a complex transform of the whole zero-imaginary block
  *                  instead of the half-length transform of the even/odd-packed block (default 1)
  *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
- *   "ols_tile"     points per workgroup of the overlap-save rows: 8192 (default), 1024 ... 4096 (tuning) or, precision 32
+ *   "ols_tile"     [lab] points per workgroup of the overlap-save rows: 8192 (default), 1024 ... 4096 (tuning) or, precision 32
  *                  only, 16384
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
@@ -287,7 +289,7 @@ int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
  * pycwt_amd.parallel uses it to cut a scale grid into cost-balanced contiguous shards.                        */
 int cwt_plan_classify(cwt_plan* plan, int mother, double param, double dt, const double* scales_host, int nrows,
                       int64_t ncols, int with_signal, int* codes);
-/* Diagnostics: with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
+/* Diagnostics (-DCWT_LAB builds; the product library never records): with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
  * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
  * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in
  * issue order, until n records are used.  Copies up to cap_records records to out_host, returns the number recorded

@@ -851,8 +851,13 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   // complex64 only: rows with K <= 512 (sorted first) on half-size workgroup tiles (store segments stay
   // >= 128 B): -6 % on this kernel; complex128 measured +7 %
   int n_half = 0;
-  if (sizeof(T) == 4 || p->narrow_small == 2) {
-    if (p->narrow_small && p->logN >= LOGP)
+#ifdef CWT_LAB
+  constexpr bool kHalfTiles64 = true;            // p->narrow_small == 2: fp64 too (measured +7 %)
+#else
+  constexpr bool kHalfTiles64 = false;
+#endif
+  if constexpr (sizeof(T) == 4 || kHalfTiles64) {
+    if (p->narrow_small && (sizeof(T) == 4 || p->narrow_small == 2) && p->logN >= LOGP)
       for (const auto& g : p->rt->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
     for (int r0 = 0; r0 < n_half; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP - 1>), dim3(1u << (p->logN - LOGP + 1), std::min(kMaxGridY, n_half - r0)),
@@ -929,15 +934,22 @@ void launch_pass_a_ct_rows_lp(cwt_plan* p, const void* in, const RowDesc* rows, 
   const size_t lds = (size_t(1) << LP) * sizeof(T);
   const Stamps sp = take_stamps(p, int64_t(grid.x) * grid.y);
   if constexpr (LP == 14) {
+#ifdef CWT_LAB
     static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, false>),
                               allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, true>), true);
+#else
+    static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, false>), true);
+#endif
     (void)once;
   }
-  if (sp.base)
+#ifdef CWT_LAB
+  if (sp.base) {
     hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, true>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
                        rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
-  else
-    hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, false>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
+    return;
+  }
+#endif
+  hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, false>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
                        rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
 }
 
@@ -977,6 +989,7 @@ void launch_pass_b_ct_lp(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, 
   const size_t lds = ((size_t(1) << LP) + (size_t(1) << (LP - 4))) * sizeof(T);
   const dim3 grid(1u << (p->logN - LP), cnt), block(1 << (LP - 4));
   const Stamps sp = CONJ ? Stamps{nullptr, 0u} : take_stamps(p, int64_t(grid.x) * grid.y);
+#ifdef CWT_LAB
   if constexpr (!CONJ) {
     if (sp.base) {
       hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, true>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
@@ -984,6 +997,7 @@ void launch_pass_b_ct_lp(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, 
       return;
     }
   }
+#endif
   hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, false>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
                      twn_of<T>(p), p->logN, W, long(ldw), long(ncols), sp);
 }
@@ -992,6 +1006,7 @@ template <typename T, int LOGK, bool CONJ>
 void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
                       const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
+#ifdef CWT_LAB
   if constexpr (!CONJ && LOGK == 10) {
     const unsigned ntiles = 1u << (p->logN - LOGP);
     if (p->pass_b_prefetch && !p->stamps && ntiles >= 32) {
@@ -1009,6 +1024,7 @@ void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int
   if constexpr (!CONJ && LOGP - 1 - LOGK >= (sizeof(T) == 8 ? 3 : 4)) {
     if (p->pass_b_small) return launch_pass_b_ct_lp<T, LOGK, LOGP - 1, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
   }
+#endif
   launch_pass_b_ct_lp<T, LOGK, LOGP, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
 }
 
@@ -1085,6 +1101,7 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   return CWT_OK;
 }
 
+#ifdef CWT_LAB
 // Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd) ...
 template <typename T, int LOGM, int LOGD>
 int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
@@ -1097,7 +1114,9 @@ int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
                        static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
   }, st);
 }
-// ... from a complex transform of half the block length (k_ols_fwd_r; block length 2^(LOGM + 1))
+#endif
+// Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd_r; block length
+// 2^(LOGM + 1)) ...
 template <typename T, int LOGM>
 int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
   const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
@@ -1110,15 +1129,20 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
 template <typename T>
 int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
   int rc = CWT_OK;
-  if (p->ols_fwd_real) {
+#ifdef CWT_LAB
+  if (p->ols_fwd_real)
+#endif
+  {
     for (int g = 0; g < 2 && !rc; ++g) {
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows) continue;
       for (int d = 0; d < 2 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
+#ifdef CWT_LAB
           case 10: rc = launch_ols_fwd_r<T, 9>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 11: rc = launch_ols_fwd_r<T, 10>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+#endif
           case 12: rc = launch_ols_fwd_r<T, 11>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 13: rc = launch_ols_fwd_r<T, 12>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 14: rc = launch_ols_fwd_r<T, 13>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
@@ -1128,6 +1152,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
     }
     return rc;
   }
+#ifdef CWT_LAB
   for (int g = 0; g < 2 && !rc; ++g) {
     const auto& G = p->rt->ols_grp[g];
     const long* nb = G.fwd_blocks;
@@ -1147,6 +1172,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
     }
   }
   return rc;
+#endif
 }
 // ... and the rows themselves (k_ols_ct)
 template <typename T, int LOGP>
@@ -1170,11 +1196,13 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows) continue;
     switch (G.logp) {
+#ifdef CWT_LAB
       case 10: rc = launch_ols_rows_p<T, 10>(p, g, W, ldw, ncols, st); break;
       case 11: rc = launch_ols_rows_p<T, 11>(p, g, W, ldw, ncols, st); break;
+      case 14: if constexpr (sizeof(T) == 4) rc = launch_ols_rows_p<T, 14>(p, g, W, ldw, ncols, st); break;
+#endif
       case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
       case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
-      case 14: if constexpr (sizeof(T) == 4) rc = launch_ols_rows_p<T, 14>(p, g, W, ldw, ncols, st); break;
       default: return fail(CWT_EINVAL, "overlap-save tile size");
     }
   }
@@ -1480,12 +1508,14 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
+#ifdef CWT_LAB
   if (!rc) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&p->side_hi, hipStreamNonBlocking, greatest) != hipSuccess)
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
+#endif
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
     if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
@@ -1551,6 +1581,12 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   if (!p || !key) return fail(CWT_EINVAL, "plan/key is NULL");
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
+#ifndef CWT_LAB
+  for (const char* lab : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched"})
+    if (k == lab)
+      return fail(CWT_EINVAL, "option " + k + " exists only in -DCWT_LAB builds of the library (tools/build_variants.py): "
+                              "a measured-and-rejected variant or a diagnostic");
+#endif
   for (auto& t : p->slots) t.key.clear();   // the classification depends on the options
   struct Restore {   // a rejected geometry leaves every geometry-affecting field as it was
     cwt_plan* p; int lmax, wg, logk, nmax;
@@ -1571,7 +1607,11 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_big") p->narrow_big = value != 0;
   else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
-  else if (k == "narrow_small") p->narrow_small = int(value);
+#ifdef CWT_LAB
+  else if (k == "narrow_small") p->narrow_small = int(value);      // 2: complex128 rows too
+#else
+  else if (k == "narrow_small") p->narrow_small = value != 0;
+#endif
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "pass_b_small") p->pass_b_small = value != 0;
   else if (k == "pass_b_prefetch") { if (value != 0 && value != 2 && value != 4) return fail(CWT_EINVAL, "pass_b_prefetch: 0, 2 or 4 tiles"); p->pass_b_prefetch = int(value); }

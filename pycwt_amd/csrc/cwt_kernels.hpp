@@ -22,8 +22,10 @@
 #ifndef CWT_MAX_THREADS
 #define CWT_MAX_THREADS 1024
 #endif
-#ifndef CWT_OLS_ABLATE
-#define CWT_OLS_ABLATE 0      // timing-only ablations of the overlap-save band kernel (tuning builds): 1 = no FFT, 2 = no stores
+// -DCWT_LAB builds (tools/build_variants.py; never the product library) add the measured-and-rejected kernel variants,
+// the phase stamps and the timing-only ablations that tools/ and DESIGN.md's experiment tables refer to.
+#if defined(CWT_LAB) && !defined(CWT_OLS_ABLATE)
+#define CWT_OLS_ABLATE 0      // timing-only ablations of the overlap-save band kernel: 1 = no FFT, 2 = no stores
 #endif
 // Minimum resident waves per SIMD the compiler must allow for (second __launch_bounds__ argument, i.e. the VGPR
 // budget: 4 -> 128, 5 -> 96, 6 -> 80, 8 -> 64 registers) of the compile-time kernels, per precision.  Measured
@@ -879,6 +881,7 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
   stamp<STAMP>(st, 4, true);
 }
 
+#ifdef CWT_LAB
 // Pass B with the loads of the next tile in flight under the FFT and the stores of the current one (option
 // "pass_b_prefetch"): every workgroup walks NTILES tiles of its row (tile v = blockIdx.x + i * gridDim.x, the same
 // XCD slice under the XCD-aware map), holding two register sets; one workgroup per CU instead of two.
@@ -935,6 +938,8 @@ k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     }
   }
 }
+
+#endif  // CWT_LAB
 
 // =============================================================================================
 // Overlap-save rows (k_ols_fwd, k_ols_ct): wide-band rows whose wavelet is COMPACT IN TIME.
@@ -1017,6 +1022,7 @@ __global__ void k_ols_gtab(const RowDesc* __restrict__ rows, Mother mo, int logP
   gt[rd.tab_off + q] = g;
 }
 
+#ifdef CWT_LAB
 // Half spectra of the input blocks of the classes with block length P_b = 2^(LOGM + LOGD) on M = 2^LOGM-point
 // workgroup tiles.  LOGD = 0: one workgroup = one block.  LOGD = 1: the first radix-2 step of a decimation-in-frequency
 // transform is done while loading -- workgroup (block, c) computes the bins 2k + c as the M-point transform of
@@ -1082,7 +1088,10 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
   if (f.j == 0 && part == 0) out[PB / 2] = mk<T>(re[8], -im[8]);
 }
 
-// The same half spectra from a complex transform of HALF the block length (the classic real-input packing): with
+#endif  // CWT_LAB
+
+// Half spectra X_b[0 .. P_b/2] of the input blocks of the overlap-save classes (x is real), from a complex transform of
+// HALF the block length (the classic real-input packing): with
 // z[n] = x[2n] + i x[2n+1], n < M = P_b / 2, and Z = FFT_M(z),
 //   X_b[k] = E[k] + e^{-2 pi i k / P_b} O[k],  E[k] = (Z[k] + conj Z[M-k]) / 2,  O[k] = (Z[k] - conj Z[M-k]) / (2i),  k <= M
 // (Z[M] = Z[0]).  One workgroup of M/16 threads per block: half the butterflies and half the registers / LDS of the
@@ -1228,14 +1237,14 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
     if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
   }
   __syncthreads();                                       // the band tile aliases the exchange buffer
-#if CWT_OLS_ABLATE != 1
+#if !defined(CWT_LAB) || CWT_OLS_ABLATE != 1
   f.run(re, im, lds, tw_all + (K - 2));
 #endif
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     // n_local = (P_b / K) (j + e NT) + r; with P_b = P this is thread + e P/16
     const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
-#if CWT_OLS_ABLATE == 2
+#if defined(CWT_LAB) && CWT_OLS_ABLATE == 2
     if (nl >= 0 && nl < nlim && re[e] == T(-1.2345e-300)) store_w<T>(wout + nl, re[e], im[e]);
 #else
     if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);

@@ -86,7 +86,7 @@ def test_mid_golden_two_pass(hip_library, name):
     x = np.random.default_rng(int(g["seed"])).standard_normal(int(g["N"]))
     kind, param = MOTHERS[name]
     for opts in (None, {"narrow": 0}, {"chunk_rows": 1}, {"wg_points": 4096}, {"lmax": 256},
-                 {"narrow": 0, "chunk_rows": 2, "overlap": 1}, {"overlap_narrow": 1}, {"ct": 0}):
+                 {"narrow": 0, "chunk_rows": 2}, {"overlap_narrow": 1}, {"ct": 0}):
         plan = _hip.Plan(int(g["N"]), 64, max_rows=32, options=opts)
         W, _ = plan.execute_host(x, kind, param, 1.0, g["sj"])
         plan.close()
@@ -440,15 +440,14 @@ def test_config5_deterministic_part_at_full_size(hip_library):
 
 
 def test_stream_overlap_options_keep_parity_at_full_size(hip_library):
-    """The optional side-stream pipelines (pass A of chunk c+1 beside pass B of chunk c through two
-    intermediate buffers; band-limited rows beside the two-pass chain) must not change a single bit."""
+    """The side-stream placement (band-limited rows beside the two-pass chain) and the chunking of the two-pass rows must
+    not change a single bit."""
     N = 1 << 20
     x = np.random.default_rng(77).standard_normal(N)
     m = orc.Mother(orc.MORLET, 6)
     sj = grid(N, 1.0, m, 256)[:160:4]                     # 40 rows, mostly two-pass
     base = None
-    for opts in ({"overlap_narrow": 0}, None, {"overlap": 1, "chunk_rows": 3}, {"overlap_narrow": 1},
-                 {"overlap": 1, "chunk_rows": 5}, {"pass_b_small": 1}):
+    for opts in ({"overlap_narrow": 0}, None, {"chunk_rows": 3}, {"overlap_narrow": 1}, {"chunk_rows": 5}):
         plan = _hip.Plan(N, 64, max_rows=64, options=opts)
         for _ in range(3):                                # repeated calls re-use the two buffers
             W = _device_rows(plan, x, orc.MORLET, 6, sj, N)
@@ -627,12 +626,11 @@ def test_overlap_save_rows_on_gpu(hip_library, name, prec, logn, n0_off):
     plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
     per_row, _ = row_errors(Wb.download(plan, (len(sj), n0), cplx), A)
     assert per_row.max() < TOL[prec]
-    if prec == 32:
-        plan.set_option("ols_tile", 16384)
-        plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
-        assert plan.last_split()["ols"] >= 8
-        per_row, _ = row_errors(Wb.download(plan, (len(sj), n0), cplx), A)
-        assert per_row.max() < TOL[prec]
+    plan.set_option("ols_small_max_halo", 0)            # every overlap-save row on the default tile
+    plan.transform(xd.ptr, n0, kind, param, 1.0, sj, xh.ptr, Wb.ptr, n0, n0)
+    assert plan.last_split()["ols"] >= 8 and not any(c.endswith("/half") for c in plan.row_classes())
+    per_row, _ = row_errors(Wb.download(plan, (len(sj), n0), cplx), A)
+    assert per_row.max() < TOL[prec]
     for b in (xd, xh, Wa, Wb):
         b.free()
     plan.close()

@@ -94,8 +94,7 @@ def ols_cases(draw):
         opts["ols_max_halo"] = draw(st.sampled_from([0, 256, 1024]))
         opts["ols_side"] = draw(st.integers(0, 1))
         opts["ols_early"] = draw(st.integers(0, 1))
-        if prec == 32:
-            opts["ols_tile"] = draw(st.sampled_from([8192, 16384]))
+        opts["ols_small_max_halo"] = draw(st.sampled_from([0, 256, 512, 1024]))
     return N, n0, kind, param, dt * np.array([2.0 ** e for e in expo]), dt, prec, opts, draw(st.integers(0, 2 ** 31))
 
 

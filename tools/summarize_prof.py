@@ -31,7 +31,7 @@ def klass(name):
     if name.startswith("k_ols_fwd"):
         return "ols_fwd"
     if name.startswith("k_ols_ct"):
-        return "ols"
+        return "ols_small" if name.rstrip(">").endswith(", 12") else "ols"     # half-size tiles (4096 points)
     for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
         if name.startswith(k):
             args = name[name.find("<") + 1:name.rfind(">")].split(", ") if "<" in name else []
