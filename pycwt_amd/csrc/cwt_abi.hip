@@ -61,6 +61,7 @@ struct Timed { int cls; hipEvent_t a, b; };
 // engine writes into a ring of page-locked slots (allocated once per plan) while a few worker threads memcpy the
 // previous chunks into the caller's memory, each thread touching its own pages.
 struct HostCopier {
+  std::mutex busy;                       // one large copy at a time per device (the copier is shared by its plans)
   static constexpr int kSlots = 3;
   static constexpr size_t kChunk = size_t(32) << 20;
   int kThreads = 8;   // worker threads: CWT_COPY_THREADS, default min(32, cores / 2) -- first-touch page faults of the
@@ -132,6 +133,27 @@ struct HostCopier {
     }
   }
 };
+
+// One copier per device for the whole process (created by the first large copy, never torn down: its worker threads and
+// pinned slots are shared by every plan of the device instead of living and dying with each plan).
+HostCopier* copier_for(int device) {
+  static std::mutex mu;
+  static std::vector<HostCopier*> all;
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0) return nullptr;
+  if (size_t(device) >= all.size()) all.resize(size_t(device) + 1, nullptr);
+  if (!all[device]) {
+    HostCopier* c = new HostCopier();
+    if (c->init() != 0) {
+      (void)hipGetLastError();
+      c->shutdown();
+      delete c;
+      return nullptr;
+    }
+    all[device] = c;
+  }
+  return all[device];
+}
 
 }  // namespace
 
@@ -232,7 +254,6 @@ struct cwt_plan {
   uint64_t tick = 0;
   int split[6] = {0, 0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
                                        // band-limited K = 2048, band-limited K = 1024 with 5..16 terms, overlap-save
-  HostCopier* copier = nullptr;       // created by the first large device -> host copy
   // Bluestein state for transform lengths n0 that are not powers of two (this plan's N is then M >= 2 n0 - 1)
   int64_t bs_n0 = 0;
   void* bs_khat[2] = {nullptr, nullptr};   // FFT_M of the chirp kernels: [0] e^{+pi i m^2/n0} (forward), [1] conjugate
@@ -1209,9 +1230,37 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
   return rc;
 }
 
+// Restores the plan's stream when a scope that redirected launches to a side stream is left on any path.
+struct StreamGuard {
+  cwt_plan* p;
+  hipStream_t keep;
+  explicit StreamGuard(cwt_plan* plan) : p(plan), keep(plan->stream) {}
+  ~StreamGuard() { p->stream = keep; }
+};
+
+template <typename T>
+int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, void* W_dev, int64_t ldw,
+                int64_t ncols, const void* x_dev, int64_t n0);
+
+// Queues every row of the current row table.  On an error after work was forked to the side streams the side streams
+// are drained before returning, so that no kernel still reads the row table, the block spectra or the filter tables when
+// the caller (or the next call) frees or rebuilds them.
 template <typename T>
 int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, void* W_dev, int64_t ldw,
               int64_t ncols, const void* x_dev = nullptr, int64_t n0 = 0) {
+  const int rc = rows_launch<T>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+  if (rc) {
+    const std::string msg = g_err;                       // the drain below must not overwrite the message
+    for (hipStream_t s : {p->side[0], p->side[1], p->side2}) if (s) (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    g_err = msg;
+  }
+  return rc;
+}
+
+template <typename T>
+int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, void* W_dev, int64_t ldw,
+                int64_t ncols, const void* x_dev, int64_t n0) {
   const int logN = p->logN;
   const cplx<T>* xhat = static_cast<const cplx<T>*>(xhat_dev);
   cplx<T>* W = static_cast<cplx<T>*>(W_dev);
@@ -1320,6 +1369,7 @@ int rows_impl(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, vo
   bool narrow_on_side = false;
   if (p->rt->n_narrow) {
     if (narrow_ct_all_applies<T>(p)) {
+      StreamGuard guard(p);                                 // p->stream is redirected below; restored on every path
       hipStream_t keep = p->stream;
       narrow_on_side = side_narrow;
       if (narrow_on_side) p->stream = p->side[0];
@@ -1401,19 +1451,13 @@ int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
     HIPCHECK(hipStreamSynchronize(p->stream));
     return CWT_OK;
   }
-  if (!p->copier) {
-    p->copier = new HostCopier();
-    if (p->copier->init() != 0) {
-      (void)hipGetLastError();
-      p->copier->shutdown();
-      delete p->copier;
-      p->copier = nullptr;
-      HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));   // no pinned memory left
-      HIPCHECK(hipStreamSynchronize(p->stream));
-      return CWT_OK;
-    }
+  HostCopier* c = copier_for(p->device);
+  if (!c) {
+    HIPCHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));   // no pinned memory left
+    HIPCHECK(hipStreamSynchronize(p->stream));
+    return CWT_OK;
   }
-  HostCopier* c = p->copier;
+  std::lock_guard<std::mutex> one_copy(c->busy);
   const size_t chunk = HostCopier::kChunk;
   const size_t nchunks = (bytes + chunk - 1) / chunk;
   char* dst = static_cast<char*>(dst_host);
@@ -1550,7 +1594,6 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
   if (p->side_hi) { (void)hipStreamSynchronize(p->side_hi); (void)hipStreamDestroy(p->side_hi); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
-  if (p->copier) { p->copier->shutdown(); delete p->copier; p->copier = nullptr; }
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
   void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->hx, p->hxhat, p->hW, p->stamps,

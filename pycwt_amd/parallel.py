@@ -39,13 +39,15 @@ _COST = {
 }
 
 
-def _shard_cost(labels, precision):
-    """Estimated step time of a rank that owns the rows with these class labels."""
+def _shard_cost(labels, precision, nscale=1.0):
+    """Estimated step time of a rank that owns the rows with these class labels.  `nscale` = transform length / 2^20:
+    the per-row parts scale with it, the fixed parts (launch ramp and tail) do not."""
     c = _COST[precision]
     total, seen = 0.0, set()
     n_two_pass = sum(1 for lab in labels if lab.startswith("two_pass"))
-    if n_two_pass > 12:                   # one launch pair per chunk of <= 12 rows (the intermediate must fit the cache)
-        total += c["two_pass"][0] * ((n_two_pass - 1) // 12)
+    chunk = max(1, int(12 / nscale))      # rows per two-pass launch pair: the intermediate must fit the Infinity Cache
+    if n_two_pass > chunk:
+        total += c["two_pass"][0] * ((n_two_pass - 1) // chunk)
     for lab in labels:
         kind = lab.split("/")[0]
         if kind.startswith("ols"):
@@ -53,6 +55,7 @@ def _shard_cost(labels, precision):
         elif kind == "single_wg":
             kind = "narrow"
         fixed, per = c[kind]
+        per *= nscale
         if kind not in seen:
             seen.add(kind)
             total += fixed
@@ -61,20 +64,21 @@ def _shard_cost(labels, precision):
             k = int(lab.split("/K")[1].split("/")[0])
             total += per * (0.11 if k >= 512 else 0.04 if k >= 128 else -0.04)
             if "/t" in lab:
-                total += c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
+                total += nscale * c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
     if seen - {"ols"}:
-        total += c["fwd"]                 # some row needs the spectrum
+        total += c["fwd"] * max(nscale, 0.5)   # some row needs the spectrum
     return total
 
 
-def balanced_shards(labels, world: int, precision: int = 64):
-    """See `_balanced_shards`; results are cached per (labels, world, precision): repeated transforms of one scale grid
-    (the normal use) pay the search once."""
-    return [np.array(s) for s in _balanced_shards(tuple(labels), world, precision)]
+def balanced_shards(labels, world: int, precision: int = 64, nfft: int = 1 << 20):
+    """See `_balanced_shards`; results are cached per (labels, world, precision, length): repeated transforms of one
+    scale grid (the normal use) pay the search once.  `nfft` = padded transform length (the cost table is fitted at 2^20;
+    per-row costs scale with the length, per-launch costs do not)."""
+    return [np.array(s) for s in _balanced_shards(tuple(labels), world, precision, float(nfft) / float(1 << 20))]
 
 
 @functools.lru_cache(maxsize=64)
-def _balanced_shards(labels, world: int, precision: int = 64):
+def _balanced_shards(labels, world: int, precision: int = 64, nscale: float = 1.0):
     """Cuts the scale grid (rows in scale order, `labels` = their kernel classes from `Plan.classify`) into `world`
     CONTIGUOUS shards of equal estimated cost.  Against interleaving (row j -> rank j mod G) a rank then runs few
     kernel classes with many rows each instead of every class with a handful -- at 8 ranks the interleaved share
@@ -92,7 +96,7 @@ def _balanced_shards(labels, world: int, precision: int = 64):
             a, b = lo, n
             while a < b:
                 m = (a + b + 1) // 2
-                if _shard_cost(labels[lo:m], precision) <= limit:
+                if _shard_cost(labels[lo:m], precision, nscale) <= limit:
                     a = m
                 else:
                     b = m - 1
@@ -101,7 +105,7 @@ def _balanced_shards(labels, world: int, precision: int = 64):
             lo = min(hi, n)
         return cuts if lo >= n else None
 
-    lo_t, hi_t = 0.0, _shard_cost(labels, precision)
+    lo_t, hi_t = 0.0, _shard_cost(labels, precision, nscale)
     for _ in range(40):
         mid = 0.5 * (lo_t + hi_t)
         if cuts_for(mid) is None:
@@ -118,11 +122,14 @@ def _balanced_shards(labels, world: int, precision: int = 64):
             lo, hi = bounds[i - 1], bounds[i + 1]
             best, best_cost = bounds[i], None
             for b in range(max(lo, bounds[i] - 4), min(hi, bounds[i] + 4) + 1):
-                cost = max(_shard_cost(labels[lo:b], precision), _shard_cost(labels[b:hi], precision))
+                cost = max(_shard_cost(labels[lo:b], precision, nscale), _shard_cost(labels[b:hi], precision, nscale))
                 if best_cost is None or cost < best_cost - 1e-9:
                     best, best_cost = b, cost
             bounds[i] = best
     return [np.arange(bounds[i], bounds[i + 1]) for i in range(world)]
+
+
+_engines: dict = {}       # default engines of cwt_sharded, one per (length, precision, device): keeps the row-table cache
 
 
 class HipEngine:
@@ -178,6 +185,12 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     (len(rows_local) x n0, complex) holding rows `rows_local` of the full transform; `sj`, `freqs`,
     `coi` describe the full transform exactly as `pycwt.cwt` returns them (after the Paul NaN-row
     rule).  One broadcast of the signal, no other collective.
+
+    `rows_local` is a contiguous run of scales of about equal estimated cost (`partition="balanced"`, one signal,
+    an engine that can classify the whole grid) or `rank, rank + world, ...` (`partition="interleaved"`, batches of
+    signals, an engine sized for its own share only, engines without `classify`): use the returned indices, do not
+    assume either.  Without `engine=` one HipEngine per (length, precision, device) is created and kept, so that
+    repeated calls re-use its classified row tables.
     """
     import torch
     import torch.distributed as dist
@@ -213,9 +226,16 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     nbatch = shape[0] if len(shape) == 2 else 1
     if engine is None:
         cap = sj.size if (partition == "balanced" and nbatch == 1) else -(-sj.size // world) * nbatch
-        engine = HipEngine(N, precision, max(1, cap), device.index or 0, device.type == "cuda")
-    if partition == "balanced" and nbatch == 1 and world > 1 and hasattr(engine, "classify"):
-        mine = balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision)[rank]
+        key = (N, precision, device.type, device.index or 0)
+        engine = _engines.get(key)
+        if engine is None or engine.plan.max_rows < cap or not engine.plan.h:
+            engine = _engines[key] = HipEngine(N, precision, max(1, cap), device.index or 0, device.type == "cuda")
+        elif device.type == "cuda":
+            engine.plan.set_stream(torch.cuda.current_stream(device.index or 0).cuda_stream)
+    # balanced shards need the classification of the WHOLE grid: an engine sized for its own share cannot give it
+    can_classify = hasattr(engine, "classify") and getattr(getattr(engine, "plan", None), "max_rows", sj.size) >= sj.size
+    if partition == "balanced" and nbatch == 1 and world > 1 and can_classify:
+        mine = balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision, N)[rank]
     else:
         mine = shard_rows(sj.size, world, rank)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)

@@ -619,6 +619,12 @@ def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, w
     coherence ratio run on the GPU without W ever leaving the device.  `sig=True` runs the Monte-Carlo
     significance of `wct_significance` (300 surrogate pairs by default, cached on disk like the
     reference); pass `sig=False` to skip it.
+
+    NOTE on the significance levels: like the reference's, they are those of WHITE surrogates -- the reference's
+    `rednoise` applies its AR(1) filter along the wrong axis (helpers.py:170) and this package reproduces that seed
+    for seed (`helpers.rednoise`).  `wct_significance(..., surrogates="ar1")` gives the levels of true AR(1) noise.
+    The default cache file carries the reference's own name and format (`wct_sig_*_<Mother>.gz`), so caches written by
+    pycwt are served and vice versa; the AR(1) variant caches under `..._ar1.gz`.
     """
     mother = _check_parameter_wavelet(wavelet)
     if not hasattr(mother, "deltaj0") or mother.deltaj0 == -1 or not isinstance(mother, Morlet):

@@ -99,10 +99,16 @@ def _kernel_worker(rank, world, port, tmpdir):
     x = np.random.default_rng(6).standard_normal(5000) if rank == 0 else None
     W, mine, sj, freqs, coi = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu)
     iw = parallel.icwt_sharded(W, sj[mine], 0.5, 1 / 4, "morlet")
+    # a caller-supplied engine sized for ITS OWN SHARE cannot classify the whole grid: interleaved rows, no error
+    small = parallel.HipEngine(8192, 64, -(-len(sj) // world), 0, on_torch_stream=False)
+    W2, mine2, *_ = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu, engine=small)
+    assert list(mine2) == list(range(rank, len(sj), world))
+    W3, mine3, *_ = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu)     # second call: cached engine
+    assert list(mine3) == list(mine) and len(parallel._engines) == 1
     X = np.random.default_rng(7).standard_normal((3, 700)) if rank == 0 else None
     Wb, mineb, sjb, _, _ = parallel.cwt_sharded(X, 1.0, 1 / 2, -1, -1, "dog", device=cpu, precision=32)
     np.savez(os.path.join(tmpdir, f"k{rank}.npz"), W=W.numpy(), mine=mine, sj=sj, iw=np.zeros(0) if iw is None else iw,
-             Wb=Wb.numpy(), mineb=mineb, sjb=sjb)
+             Wb=Wb.numpy(), mineb=mineb, sjb=sjb, W2=W2.numpy(), mine2=mine2, W3=W3.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -121,6 +127,9 @@ def test_two_ranks_run_the_real_kernels_through_the_c_abi(tmp_path):
     for q in r:
         full[q["mine"]] = q["W"]
     assert np.abs(full - W).max() < 1e-12 * np.abs(W).max()
+    for q in r:
+        assert np.abs(q["W2"] - W[q["mine2"]]).max() < 1e-12 * np.abs(W).max()
+        assert np.array_equal(q["W3"], q["W"])
     np.testing.assert_allclose(r[0]["iw"], orc.icwt(W, sj, 0.5, 1 / 4, "morlet"), rtol=1e-10, atol=1e-12)
     X = np.random.default_rng(7).standard_normal((3, 700))
     for b in range(3):
