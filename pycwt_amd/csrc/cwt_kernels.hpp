@@ -42,6 +42,12 @@
 #ifndef CWT_LB_OLS_F32
 #define CWT_LB_OLS_F32 6      // 80 VGPRs -> three 512-thread workgroups per CU: overlap-save kernel -7 % (fp32 DOG / Paul)
 #endif
+#ifndef CWT_LB_OLS_F32_HALF
+#define CWT_LB_OLS_F32_HALF 6 // the same kernel on half-size tiles (256 threads)
+#endif
+#ifndef CWT_LB_OLS_F64_HALF
+#define CWT_LB_OLS_F64_HALF 4
+#endif
 #ifndef CWT_LB_PASS_A_F64
 #define CWT_LB_PASS_A_F64 4
 #endif
@@ -1256,7 +1262,8 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
 // inside a class the 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of a block back to back, so that
 // a block spectrum is fetched into one L2 once and read there by every row.
 template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_OLS_F64 : CWT_LB_OLS_F32))
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64)
+                                                                : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
 k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ gtab,
          const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, OlsClasses cls, cplx<T>* __restrict__ W, long ldw,
          long ncols) {

@@ -28,14 +28,15 @@ def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
     return np.arange(rank, nrows, world)
 
 
-# Cost model of one rank's step, microseconds at N = 2^20 (everything scales with N): a fixed part per kernel class
-# that has at least one row (launch ramp and tail, the forward FFT, the block spectra) plus a per-row part.  Fitted
-# to the measured launch durations of bench.py at 1/8 .. 8/8 of BASELINE config 2 / 3.
+# Cost model of one rank's step, microseconds at N = 2^20: a fixed part per kernel class that has at least one row
+# (launch ramp and tail; for the overlap-save classes the block spectra of that tile size) plus a per-row part.  Fitted
+# to the per-class launch durations of bench.py on BASELINE config 2 / 3 (round 3: `roofline.per_class` of
+# profiles/r03_bench_default.json, and the per-rank runs of profiles/r03_shards.txt).
 _COST = {
-    64: {"fwd": 27.0, "two_pass": (30.0, 7.0), "narrow_k2048": (20.0, 5.4), "ols": (33.0, 4.0), "narrow": (4.0, 2.8),
-         "narrow_t": 1.0},
-    32: {"fwd": 27.0, "two_pass": (25.0, 4.6), "narrow_k2048": (20.0, 5.4), "ols": (30.0, 2.5), "narrow": (4.0, 1.7),
-         "narrow_t": 0.5},
+    64: {"fwd": 28.0, "two_pass": (18.0, 9.8), "narrow_k2048": (8.0, 5.9), "ols": (27.0, 3.9), "ols_half": (23.0, 3.5),
+         "narrow": (5.0, 2.85), "narrow_t": 0.9},
+    32: {"fwd": 27.0, "two_pass": (14.0, 5.3), "narrow_k2048": (8.0, 5.4), "ols": (28.0, 2.3), "ols_half": (20.0, 1.9),
+         "narrow": (4.0, 1.75), "narrow_t": 0.55},
 }
 
 
@@ -51,7 +52,7 @@ def _shard_cost(labels, precision, nscale=1.0):
     for lab in labels:
         kind = lab.split("/")[0]
         if kind.startswith("ols"):
-            kind = "ols"
+            kind = "ols_half" if lab.endswith("/half") else "ols"
         elif kind == "single_wg":
             kind = "narrow"
         fixed, per = c[kind]
@@ -62,10 +63,10 @@ def _shard_cost(labels, precision, nscale=1.0):
         total += per
         if kind == "narrow" and "/K" in lab:             # longer transforms per residue, shorter store segments
             k = int(lab.split("/K")[1].split("/")[0])
-            total += per * (0.11 if k >= 512 else 0.04 if k >= 128 else -0.04)
+            total += per * (0.25 if k >= 1024 else 0.13 if k >= 512 else 0.05 if k >= 32 else -0.05)
             if "/t" in lab:
                 total += nscale * c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
-    if seen - {"ols"}:
+    if seen - {"ols", "ols_half"}:
         total += c["fwd"] * max(nscale, 0.5)   # some row needs the spectrum
     return total
 
