@@ -62,6 +62,16 @@ __device__ __forceinline__ void keep_here(T& v) {
 #endif
 }
 
+// stage twiddle e^{2 pi i idx / L} from the table (timing-only lab ablation: arithmetic instead of the load)
+template <typename T>
+__device__ __forceinline__ cplx<T> stage_tw(const cplx<T>* __restrict__ tw, int idx) {
+#if defined(CWT_LAB) && defined(CWT_ABLATE_STAGE_TW)
+  return mk<T>(T(1) - T(idx) * T(1e-9), T(idx) * T(1e-9));
+#else
+  return tw[idx];
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ cplx<T> cmul(cplx<T> a, cplx<T> b) {
   return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -220,7 +230,7 @@ __device__ __forceinline__ void partial_stage(T (&re)[16], T (&im)[16], int j, i
   for (int u = 0; u < NB; ++u) {
     const int jj = j + (u << logNT);
     const int k = jj & ((1 << logNs) - 1);
-    const cplx<T> w = tw[k << (logL - logNs - LOGR)];
+    const cplx<T> w = stage_tw<T>(tw, k << (logL - logNs - LOGR));
     T lr[R], li[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) { lr[i] = re[u + i * NB]; li[i] = im[u + i * NB]; }
@@ -246,7 +256,7 @@ __device__ __forceinline__ void wg_ifft(T (&re)[16], T (&im)[16], T* lds, const 
   for (int s = 0; s < nfull; ++s) {
     const int k = g.j & ((1 << logNs) - 1);
     if (s > 0) {
-      const cplx<T> w = tw[k << (logL - logNs - 4)];
+      const cplx<T> w = stage_tw<T>(tw, k << (logL - logNs - 4));
       twiddle_chain<T, 16>(re, im, w.x, w.y);
     }
     bfly16<T>(re, im);
@@ -343,7 +353,7 @@ struct Fft {
     constexpr int LOGNS = 4 * S;
     const int k = j & ((1 << LOGNS) - 1);
     if constexpr (S > 0) {
-      const cplx<T> w = tw[k << (LOGL - LOGNS - 4)];
+      const cplx<T> w = stage_tw<T>(tw, k << (LOGL - LOGNS - 4));
       twiddle_chain<T, 16>(re, im, w.x, w.y);
     }
     bfly16<T>(re, im);
