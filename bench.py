@@ -14,6 +14,11 @@ default) or row j -> rank j mod G (`--partition interleaved`) -- (STRONG scaling
 travelling while step i computes; there is no other collective.  `--weak` (and the `weak_scaling` block of the
 default multi-GPU line) refines the grid to 256*G rows instead, 256 per GPU.
 
+Clocks: this GPU idles at sclk ~0.5 GHz and needs ~45 ms of work to reach its sustained clock (tools/clock_ramp.py), more
+than the W warm-up steps of a short run last.  bench.py therefore runs an untimed priming phase (>= 80 ms of the same
+steps) BEFORE the W warm-up steps; W and K are honoured exactly.  The same W + K steps started from the idle device are
+measured first and reported as `from_idle`; `--no-prime` makes that the headline.
+
 Rank 0 prints ONE JSON line with the driver's contract fields plus
   roofline      dominant kernel, HIP-event timed inside this process in a separate pass
   parity        (1 GPU) every row of W of the timed workload against the CPU oracle: max per-row error, worst
@@ -210,6 +215,21 @@ class Workload:
         ms = elapsed / steps * 1e3
         return {"ms_per_step": ms, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9}
 
+    def prime(self, min_ms):
+        """Untimed steps until at least `min_ms` of wall time have passed: brings the device from its idle clock to its
+        sustained clock (DPM ramps over the first ~45 ms of work; measured with tools/clock_ramp.py: 1.23 ms per step
+        for the first 10 steps after idle, 1.09 for the next 10, 1.03 from the 40th on).  Returns the steps run."""
+        rt, done = self.rt, 0
+        rt.fence()
+        t0 = time.perf_counter()
+        while True:
+            self.run_steps(8)
+            rt.fence()
+            done += 8
+            spent = rt.max_over_ranks(time.perf_counter() - t0) * 1e3
+            if spent >= min_ms or done >= 4096:
+                return done
+
     def roofline(self, steps):
         """Per-kernel HIP-event timing in separate passes (option "profile": every kernel alone on the plan's
         stream, so that each duration is its own) -> achieved algorithmic bandwidth of every kernel class and of the
@@ -278,7 +298,8 @@ class Workload:
         return {
             "bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            # the honest headline: ALL algorithmic bytes of the step over the sum of all kernel times
+            # the honest headline: ALL algorithmic bytes of the step over the timed step (set by measure(); here: over the
+            # sum of all kernel times of the profiling pass)
             "whole_path_frac": whole["frac"],
             "traffic": traffic,
             # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this command, collected
@@ -406,10 +427,31 @@ class Workload:
             lane[0].close()
 
 
+PRIME_MS = 80.0     # untimed device work before the W warm-up steps, see prime()
+
+
 def measure(rt, config, args, rows_total, opts, want_cpu):
     wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
-    out = wl.timed(args.steps, args.warmup)
+    if args.prime and not args.emulate:
+        # the same W + K steps first from an idle device (reported as `from_idle`), then with the clocks up (the headline)
+        idle = wl.timed(args.steps, args.warmup)
+        primed_steps = wl.prime(PRIME_MS)
+        out = wl.timed(args.steps, args.warmup)
+        out["from_idle"] = {"ms_per_step": idle["ms_per_step"], "value": idle["value"],
+                            "note": "the same W warm-up + K timed steps started on an idle device (clocks still ramping)"}
+        out["clock_priming"] = (f"{primed_steps} untimed steps (>= {PRIME_MS:.0f} ms of work) before the W warm-up steps: this "
+                                "GPU needs ~45 ms of work to go from its idle clock (sclk ~0.5 GHz) to its sustained clock "
+                                "(tools/clock_ramp.py, profiles/r03_clock_ramp.txt); the K timed steps are unchanged")
+    else:
+        out = wl.timed(args.steps, args.warmup)
     out["roofline"] = wl.roofline(args.steps)
+    wp = out["roofline"].get("whole_path")
+    if wp:
+        # the headline fraction: this GPU's algorithmic bytes of a step over the TIMED step (wall clock of the K steps);
+        # `whole_path.frac` prices the same bytes over the sum of the kernels' own durations in the profiling pass (every
+        # kernel alone between two HIP events, which costs a few microseconds per launch)
+        wp["frac_of_timed_step"] = wp["algorithmic_bytes_per_step_per_gpu"] / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["whole_path_frac"] = wp["frac_of_timed_step"]
     if not wl.sharded and not rt.use_dist:
         out["cold_grid_ms"] = wl.cold_grid()
     if want_cpu:
@@ -446,6 +488,9 @@ def main():
                          "--force-dist broadcast if given; `value` is then what G such ranks would deliver together")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="diagnostic: this many signals in flight (step i on plan / stream / W buffer i mod P); the headline is 1")
+    ap.add_argument("--no-prime", dest="prime", action="store_false",
+                    help="do not bring the device to its sustained clocks before the W warm-up steps (then `value` is what "
+                         "`from_idle` reports otherwise)")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
@@ -489,9 +534,11 @@ def main():
         # one step with a scale grid the plan has not seen (host classification + table upload + filter tables + step);
         # ms_per_step is the steady state with the row table cached
         out["cold_grid_ms"] = head["cold_grid_ms"]
-    for k in ("parity", "cpu_baseline"):
+    for k in ("parity", "cpu_baseline", "from_idle"):
         if k in head:
             out[k] = head[k]
+    if "clock_priming" in head:
+        out["config"]["clock_priming"] = head["clock_priming"]
     if world > 1 and not args.weak:
         # same run, weak-scaling variant (per-GPU work fixed): --rows rows per GPU of a rows*G-row grid
         weak = measure(rt, args.config, args, args.rows * world, opts, want_cpu=False)
@@ -505,7 +552,7 @@ def main():
                                "value": r["value"], "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"],
                                "dtype": r["dtype"], "steps": args.steps, "warmup": args.warmup, "tolerance": r["tolerance"],
                                "roofline": r["roofline"], "parity": r["parity"], "cpu_baseline": r["cpu_baseline"],
-                               "cold_grid_ms": r.get("cold_grid_ms")}
+                               "cold_grid_ms": r.get("cold_grid_ms"), "from_idle": r.get("from_idle")}
     rt.close()
     import ctypes
     sys.stdout.flush()
