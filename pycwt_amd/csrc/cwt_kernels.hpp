@@ -1240,7 +1240,9 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
     re[e] = y.x * cur.x - y.y * cur.y;
     im[e] = y.x * cur.y + y.y * cur.x;
     if (e < 15) cur = cmul<T>(cur, step);
+#if !(defined(CWT_LAB) && defined(CWT_ABLATE_WRAP))                      // (timing-only lab ablation: no alias wrap)
     if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
+#endif
   }
   __syncthreads();                                       // the band tile aliases the exchange buffer
 #if !defined(CWT_LAB) || CWT_OLS_ABLATE != 1
@@ -1252,6 +1254,8 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
     const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
 #if defined(CWT_LAB) && CWT_OLS_ABLATE == 2
     if (nl >= 0 && nl < nlim && re[e] == T(-1.2345e-300)) store_w<T>(wout + nl, re[e], im[e]);
+#elif defined(CWT_LAB) && defined(CWT_ABLATE_PRED)
+    store_w<T>(wout + max(0, min(nl, nlim - 1)), re[e], im[e]);        // timing only: clamped index, no predicated store
 #else
     if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
 #endif

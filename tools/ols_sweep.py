@@ -20,10 +20,12 @@ for s in (5.0, 6.0, 8.0, 12.0, 16.0, 24.0, 32.0, 48.0, 64.0, 90.0, 128.0, 180.0,
     plan = _hip.Plan(N, args.prec, max_rows=rows, options=dict(opts, profile=1))
     xd.upload(plan, x)
     sj = np.full(rows, s)
-    for _ in range(3):
+    t_warm = __import__("time").perf_counter()       # bring the device to its sustained clock first (tools/clock_ramp.py)
+    while __import__("time").perf_counter() - t_warm < 0.12:
         plan.transform(xd.ptr, N, args.mother, param, dt, sj, xh.ptr, W.ptr, N, N)
+        plan.sync()
     plan.sync(); plan.timings()
-    reps = 5
+    reps = 20
     for _ in range(reps):
         plan.transform(xd.ptr, N, args.mother, param, dt, sj, xh.ptr, W.ptr, N, N)
     tm = plan.timings()
