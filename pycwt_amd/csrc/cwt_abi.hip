@@ -177,6 +177,7 @@ struct cwt_plan {
   int big_terms = 6;       // ... and at K = 2048 (fp64, 16384-point workgroups; <= 8)
   int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
+  int narrow_wave = 0;     // [lab] band-limited rows with K <= 128 on the barrier-free kernel (one transform per wavefront)
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
   int force_logk = 0;
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
@@ -869,6 +870,17 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   const int first = p->rt->narrow_groups.front().first;
   int n_small_k, n_big;
   narrow_class_counts(p, &n_small_k, &n_big);
+  int n_wave = 0;
+#ifdef CWT_LAB
+  // rows with K <= 128 and one term (sorted first) on the barrier-free kernel, one transform per wavefront (measured slower)
+  if (p->narrow_wave && p->logN >= LOGP)
+    for (const auto& g : p->rt->narrow_groups) if (g.logK <= 7 && g.nterms == 1) n_wave += g.count;
+  for (int r0 = 0; r0 < n_wave; r0 += kMaxGridY)
+    hipLaunchKernelGGL((k_narrow_wave<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_wave - r0)),
+                       dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
+                       p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
+                       p->logN, W, long(ldw), long(ncols));
+#endif
   // complex64 only: rows with K <= 512 (sorted first) on half-size workgroup tiles (store segments stay
   // >= 128 B): -6 % on this kernel; complex128 measured +7 %
   int n_half = 0;
@@ -880,13 +892,14 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   if constexpr (sizeof(T) == 4 || kHalfTiles64) {
     if (p->narrow_small && (sizeof(T) == 4 || p->narrow_small == 2) && p->logN >= LOGP)
       for (const auto& g : p->rt->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
-    for (int r0 = 0; r0 < n_half; r0 += kMaxGridY)
+    n_half = std::max(n_half, n_wave);
+    for (int r0 = n_wave; r0 < n_half; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP - 1>), dim3(1u << (p->logN - LOGP + 1), std::min(kMaxGridY, n_half - r0)),
                          dim3(1 << (LOGP - 5)), (size_t(1) << (LOGP - 1)) * sizeof(T), p->stream, xhat,
                          p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
                          p->logN, W, long(ldw), long(ncols));
   }
-  for (int r0 = n_half; r0 < n_small_k; r0 += kMaxGridY)
+  for (int r0 = std::max(n_half, n_wave); r0 < n_small_k; r0 += kMaxGridY)
     hipLaunchKernelGGL((k_narrow_ct_all<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_small_k - r0)),
                        dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
                        p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
@@ -1625,7 +1638,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
 #ifndef CWT_LAB
-  for (const char* lab : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched"})
+  for (const char* lab : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched",
+                          "narrow_wave"})
     if (k == lab)
       return fail(CWT_EINVAL, "option " + k + " exists only in -DCWT_LAB builds of the library (tools/build_variants.py): "
                               "a measured-and-rejected variant or a diagnostic");
@@ -1648,6 +1662,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
+  else if (k == "narrow_wave") p->narrow_wave = value != 0;
   else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
 #ifdef CWT_LAB

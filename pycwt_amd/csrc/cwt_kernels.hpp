@@ -645,6 +645,83 @@ k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 #undef CWT_NARROW_CASE
 }
 
+#ifdef CWT_LAB
+// (measured slower than the workgroup kernel in both precisions -- K = 16 ... 128: 2.90 / 3.34 / 3.19 / 3.33 against
+// 2.73 / 3.22 / 3.08 / 3.14 us per row in fp64 -- the barriers are not what these rows wait for, and every wave rebuilds
+// the band; kept for the record, lab builds only)
+// Band-limited rows with K <= 128, one aliased term: the K/16 <= 8 threads of a transform sit in ONE wavefront (lane =
+// thread-in-transform * RW + residue, RW = 64 / (K/16) residues per wave), so the exchange of the radix-16 stage and the
+// build of the filtered band need only wave-level synchronisation: no workgroup barrier anywhere, the 8 (fp64) / 16
+// (fp32) waves of a workgroup run on their own and their compute and store phases interleave freely.  Every wave builds
+// the row's band (K <= 128 bins, at most two filter evaluations per lane) in its own LDS slice, which the exchange then
+// re-uses.  Same grid, same residues per workgroup (8192 / 16384 points) and the same stores as k_narrow_ct_all: a store
+// instruction writes K/16 segments of RW x sizeof(complex) = 1 KiB ... 128 bytes.
+template <typename T, int LOGK, int LOGP>
+__device__ __forceinline__ void narrow_wave_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd, const Mother& mo,
+                                                 const cplx<T>* __restrict__ tw_all, const TwN<T>& twn, int logN,
+                                                 cplx<T>* __restrict__ W, long ldw, long ncols, T* lds_wg) {
+  constexpr int K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, LOGRW = 6 - LOGNT, RW = 1 << LOGRW;
+  constexpr int LOGWAVES = LOGP - 10;                       // waves per workgroup: 2^(LOGP - 4) threads / 64
+  static_assert(LOGK >= 4 && LOGK <= 7, "K = 16 .. 128");
+  using F = ct::Fft<T, LOGK, LOGRW, true, false, true>;
+  const int N = 1 << logN, logR = logN - LOGK;
+  const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+  T* lds = lds_wg + wave * (K * RW);                        // this wave's slice: K * RW = 1024 reals
+  F f;
+  f.t = lane & (RW - 1);
+  f.j = lane >> LOGRW;
+  const unsigned r = (((xcd_tile<T>() << LOGWAVES) + unsigned(wave)) << LOGRW) + unsigned(f.t);
+  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
+  for (int q = lane; q < K; q += 64) {
+    const int dq = (q - rd.k_lo) & (K - 1);
+    ytile[q] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + dq, N - 1);
+  }
+  F::sync();
+  const unsigned nm = unsigned(N - 1);
+  const cplx<T> step = twn((unsigned(NT) * r) & nm);
+  const cplx<T> rho = twn((r << LOGK) & nm);
+  const cplx<T> stepw = cmul<T>(step, mk<T>(rho.x, -rho.y));
+  int d = (f.j - rd.k_lo) & (K - 1);
+  cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> y = ytile[f.j + e * NT];
+    re[e] = y.x * cur.x - y.y * cur.y;
+    im[e] = y.x * cur.y + y.y * cur.x;
+    const int dn = (d + NT) & (K - 1);
+    cur = cmul<T>(cur, dn < d ? stepw : step);
+    d = dn;
+  }
+  F::sync();                                                // the band aliases the exchange slice
+  f.run(re, im, lds, tw_all + (K - 2));
+  cplx<T>* wrow = W + long(rd.out_row) * ldw;
+  const unsigned off = (unsigned(f.j) << logR) + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const unsigned step_e = unsigned(e * NT) << logR;
+    if (long(off) + step_e < ncols) store_w<T>(wrow + step_e + off, re[e], im[e]);
+  }
+}
+
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
+k_narrow_wave(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
+              const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+  switch (rd.logK) {
+    case 4: narrow_wave_body<T, 4, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 5: narrow_wave_body<T, 5, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 6: narrow_wave_body<T, 6, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    case 7: narrow_wave_body<T, 7, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
+    default: break;
+  }
+}
+
+#endif  // CWT_LAB
+
 // Band-limited rows with 5..16 aliased terms of K = 1024 bins (support up to 16384 bins): a kernel of their own so
 // that the common cases above keep their register allocation.
 template <typename T, int LOGP>

@@ -302,11 +302,14 @@ __device__ __forceinline__ void wave_sync() {
 // Without it the stage-0 writes of a workgroup with few FFTs (lanes 16*TB elements apart) all fall on the same banks
 // (32-way conflict at TB = 2, 16-way at TB = 4); with it lane pairs are 17*TB apart.  Offsets stay immediates: every
 // stride is a multiple of 16 elements except the stage-0 slot stride TB, whose pad (n*TB) >> 4 does not depend on t.
-template <typename T, int LOGL, int LOGTB, bool PLANES, bool PADDED = false>
+// WAVE (PLANES only): the TB FFTs of this instance live inside ONE wavefront (TB * L / 16 <= 64 threads, lds = that
+// wave's own slice): wave-level synchronisation instead of workgroup barriers, so the waves of a workgroup run on their own.
+template <typename T, int LOGL, int LOGTB, bool PLANES, bool PADDED = false, bool WAVE = false>
 struct Fft {
   static constexpr int L = 1 << LOGL, TB = 1 << LOGTB, LOGNT = LOGL - 4, NT = 1 << LOGNT;
   static constexpr int NFULL = LOGL / 4, REM = LOGL % 4;
-  static constexpr bool WAVE_LOCAL = !PLANES && NT <= 64;   // every FFT lives inside one wavefront
+  static constexpr bool WAVE_LOCAL = (!PLANES && NT <= 64) || WAVE;   // every FFT lives inside one wavefront
+  static_assert(!WAVE || (PLANES && (TB * NT <= 64)), "WAVE: all FFTs of the instance inside one wavefront");
   static_assert(PLANES || LOGL >= 8, "ROWS layout needs L >= 256");
   static_assert(!PADDED || (PLANES && LOGTB <= 3 && LOGL + LOGTB >= 8), "padded planes: TB <= 8, tile >= 256");
   static constexpr int LDS_ELEMS = (PLANES && !PADDED) ? (TB * L) : (TB * L + ((TB * L) >> 4));
