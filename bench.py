@@ -156,7 +156,7 @@ class Workload:
             # whole grid -- host arithmetic, identical on all ranks -- and takes its run of scales
             from pycwt_amd.parallel import balanced_shards
             labels = self.plan.classify(self.kind, self.param, self.dt, self.sj_all, self.N, True)
-            self.mine = balanced_shards(labels, rt.shard[1], self.prec, self.N)[rt.shard[0]]
+            self.mine = balanced_shards(labels, rt.shard[1], self.prec, self.N, lib=rt.lib)[rt.shard[0]]
         else:
             self.mine = np.arange(rt.shard[0], rows_total, rt.shard[1])
         self.sj = np.ascontiguousarray(self.sj_all[self.mine])

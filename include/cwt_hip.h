@@ -289,6 +289,23 @@ int cwt_plan_row_classes(cwt_plan* plan, int* codes, int cap, int* n);
  * pycwt_amd.parallel uses it to cut a scale grid into cost-balanced contiguous shards.                        */
 int cwt_plan_classify(cwt_plan* plan, int mother, double param, double dt, const double* scales_host, int nrows,
                       int64_t ncols, int with_signal, int* codes);
+/* ---- multi-GPU hosts ------------------------------------------------------
+ * Rows (scales) of one transform are independent given the signal (wavelet.py:102-106), so a host in ANY language shards
+ * them over its GPUs -- one plan per GPU, every rank calling cwt_transform on its own contiguous run of `scales`, the
+ * signal broadcast once with whatever collective the host uses (pycwt_amd.parallel: RCCL through torch.distributed).
+ * cwt_plan_balanced_shards cuts the grid into `world` CONTIGUOUS runs of about equal estimated cost: it classifies the rows
+ * as cwt_transform would and prices a run as a per-launch part per kernel class present + a per-row part (fitted to
+ * measured launch durations, profiles/r03_per_class.txt; per-row parts scale with nfft, the two-pass chunk limit is the
+ * plan's own).  first[r], count[r] (r < world) = rank r's rows; identical on every rank (host arithmetic only).
+ * cwt_shard_codes is the same search on row-class codes (cwt_plan_row_classes / cwt_plan_classify) without a plan:
+ * nscale = nfft / 2^20, chunk_rows = rows per two-pass launch pair.                                                   */
+int cwt_plan_balanced_shards(cwt_plan* plan, int mother, double param, double dt, const double* scales_host, int nrows,
+                             int64_t ncols, int world, int* first, int* count);
+int cwt_shard_codes(const int* codes, int nrows, int precision, double nscale, int chunk_rows, int world, int* first,
+                    int* count);
+/* The model's estimate (microseconds per step) for a rank that owns exactly the rows with these codes. */
+int cwt_shard_cost(const int* codes, int nrows, int precision, double nscale, int chunk_rows, double* cost_us);
+
 /* Diagnostics (-DCWT_LAB builds; the product library never records): with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
  * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
  * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in

@@ -67,6 +67,11 @@ SYMBOLS = [
                                     C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("cwt_plan_balanced_shards", C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int64,
+                                           C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("cwt_shard_codes", C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
+    ("cwt_shard_cost", C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     ("cwt_plan_set_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_plan_get_tolerance", C.c_int, [_P, C.POINTER(C.c_double)]),
 ]
@@ -342,6 +347,37 @@ class Plan:
         self.lib.check(self.lib.cwt_plan_classify(self.h, mother, float(param), float(dt), _dptr(s), s.size, ncols,
                                                   int(with_signal), codes))
         return self._labels(codes[:s.size])
+
+    @_locked
+    def balanced_shards(self, mother: int, param: float, dt: float, scales, ncols: int, world: int):
+        """Contiguous cost-balanced shards of the scale grid for `world` ranks (cwt_plan_balanced_shards): list of index
+        arrays, identical on every rank."""
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        first, count = (C.c_int * world)(), (C.c_int * world)()
+        self.lib.check(self.lib.cwt_plan_balanced_shards(self.h, mother, float(param), float(dt), _dptr(s), s.size, ncols,
+                                                         world, first, count))
+        return [np.arange(first[r], first[r] + count[r]) for r in range(world)]
+
+    @staticmethod
+    def codes_of(labels):
+        """Inverse of `_labels`: row-class codes of label strings."""
+        out = []
+        for lab in labels:
+            parts = lab.split("/")
+            if parts[0] == "single_wg":
+                out.append(0)
+            elif parts[0] == "two_pass":
+                out.append(30000 + (0 if parts[1] == "full" else int(np.log2(int(parts[1][1:])))) * 100 + 1)
+            elif parts[0] == "narrow_k2048":
+                out.append(20000 + 1100 + int(parts[1][1:]))
+            elif parts[0].startswith("ols"):
+                terms = int(parts[0][3:]) if len(parts[0]) > 3 else 1
+                kind = 5 if parts[-1] == "half" else 4
+                out.append(kind * 10000 + int(np.log2(int(parts[1][1:]))) * 100 + terms)
+            else:
+                terms = int(parts[2][1:]) if len(parts) > 2 else 1
+                out.append(10000 + int(np.log2(int(parts[1][1:]))) * 100 + terms)
+        return out
 
     @staticmethod
     def _labels(codes):

@@ -2410,6 +2410,112 @@ int cwt_plan_classify(cwt_plan* p, int mother, double param, double dt, const do
   return cwt_plan_row_classes(p, codes, nrows, &n);
 }
 
+extern "C++" {
+namespace {
+// Cost model of one rank's step, microseconds at N = 2^20: per kernel class a fixed part (launch ramp and tail; for the
+// overlap-save classes the block spectra of that tile size) + a per-row part.  Fitted to the per-class launch durations of
+// bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt.
+struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term; };
+constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 8.0, 5.9, 27.0, 3.9, 23.0, 3.5, 5.0, 2.85, 0.9};
+constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55};
+
+// Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
+// length / 2^20: per-row parts scale with it, per-launch parts do not; chunk = rows per two-pass launch pair.
+double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double nscale, int chunk) {
+  double total = 0;
+  bool seen_tp = false, seen_big = false, seen_ols = false, seen_olsh = false, seen_nar = false;
+  int n_tp = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int kind = codes[i] / 10000, logk = (codes[i] / 100) % 100, terms = codes[i] % 100;
+    if (kind == 3) { ++n_tp; if (!seen_tp) { seen_tp = true; total += c.tp_fixed; } total += c.tp_row * nscale; }
+    else if (kind == 2) { if (!seen_big) { seen_big = true; total += c.k2048_fixed; } total += c.k2048_row * nscale; }
+    else if (kind == 4) { if (!seen_ols) { seen_ols = true; total += c.ols_fixed; } total += c.ols_row * nscale; }
+    else if (kind == 5) { if (!seen_olsh) { seen_olsh = true; total += c.olsh_fixed; } total += c.olsh_row * nscale; }
+    else {
+      if (!seen_nar) { seen_nar = true; total += c.nar_fixed; }
+      const double per = c.nar_row * nscale;
+      total += per;
+      if (kind == 1) {                      // longer transforms per residue, shorter store segments
+        const int K = 1 << logk;
+        total += per * (K >= 1024 ? 0.25 : K >= 512 ? 0.13 : K >= 32 ? 0.05 : -0.05);
+        if (terms > 1) total += nscale * c.nar_term * (terms - 1);
+      }
+    }
+  }
+  if (n_tp > chunk) total += c.tp_fixed * ((n_tp - 1) / chunk);
+  if (seen_tp || seen_big || seen_nar) total += c.fwd * std::max(nscale, 0.5);   // some row needs the spectrum
+  return total;
+}
+}  // namespace
+}  // extern "C++"
+
+int cwt_shard_codes(const int* codes, int nrows, int precision, double nscale, int chunk_rows, int world, int* first,
+                    int* count) {
+  if (!codes || !first || !count) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 0 || world < 1 || (precision != 32 && precision != 64) || !(nscale > 0) || chunk_rows < 1)
+    return fail(CWT_EINVAL, "bad shard arguments");
+  const ShardCost& c = precision == 64 ? kShardCost64 : kShardCost32;
+  const int n = nrows;
+  std::vector<int> bounds(size_t(world) + 1, n);
+  bounds[0] = 0;
+  if (world > 1 && n > 0) {
+    // largest shard minimised by bisection on the limit: greedy fill of contiguous shards (cost is monotone in hi)
+    auto cuts_for = [&](double limit, std::vector<int>* out) {
+      int lo = 0;
+      for (int r = 0; r < world; ++r) {
+        int a = lo, b = n;
+        while (a < b) {
+          const int m = (a + b + 1) / 2;
+          if (shard_cost(codes, lo, m, c, nscale, chunk_rows) <= limit) a = m; else b = m - 1;
+        }
+        const int hi = lo < n ? std::max(a, lo + 1) : lo;
+        if (out) (*out)[size_t(r) + 1] = std::min(hi, n);
+        lo = std::min(hi, n);
+      }
+      return lo >= n;
+    };
+    double lo_t = 0, hi_t = shard_cost(codes, 0, n, c, nscale, chunk_rows);
+    for (int it = 0; it < 40; ++it) {
+      const double mid = 0.5 * (lo_t + hi_t);
+      if (cuts_for(mid, nullptr)) hi_t = mid; else lo_t = mid;
+    }
+    cuts_for(hi_t, &bounds);
+    bounds[size_t(world)] = n;
+    // the greedy fill leaves the slack in the last shard and may strand one or two rows of a kernel class in a shard:
+    // move every boundary by up to 4 rows where that lowers the larger of the two neighbouring shards
+    for (int pass = 0; pass < 3; ++pass)
+      for (int i = 1; i < world; ++i) {
+        const int lo = bounds[size_t(i) - 1], hi = bounds[size_t(i) + 1];
+        int best = bounds[size_t(i)];
+        double best_cost = -1;
+        for (int b = std::max(lo, bounds[size_t(i)] - 4); b <= std::min(hi, bounds[size_t(i)] + 4); ++b) {
+          const double cost = std::max(shard_cost(codes, lo, b, c, nscale, chunk_rows), shard_cost(codes, b, hi, c, nscale, chunk_rows));
+          if (best_cost < 0 || cost < best_cost - 1e-9) { best = b; best_cost = cost; }
+        }
+        bounds[size_t(i)] = best;
+      }
+  }
+  for (int r = 0; r < world; ++r) { first[r] = bounds[size_t(r)]; count[r] = bounds[size_t(r) + 1] - bounds[size_t(r)]; }
+  return CWT_OK;
+}
+
+int cwt_shard_cost(const int* codes, int nrows, int precision, double nscale, int chunk_rows, double* cost_us) {
+  if (!codes || !cost_us) return fail(CWT_EINVAL, "NULL argument");
+  if (nrows < 0 || (precision != 32 && precision != 64) || !(nscale > 0) || chunk_rows < 1)
+    return fail(CWT_EINVAL, "bad shard arguments");
+  *cost_us = shard_cost(codes, 0, nrows, precision == 64 ? kShardCost64 : kShardCost32, nscale, chunk_rows);
+  return CWT_OK;
+}
+
+int cwt_plan_balanced_shards(cwt_plan* p, int mother, double param, double dt, const double* scales, int nrows,
+                             int64_t ncols, int world, int* first, int* count) {
+  if (!p || !scales || !first || !count) return fail(CWT_EINVAL, "NULL argument");
+  std::vector<int> codes(size_t(std::max(nrows, 1)));
+  int rc = cwt_plan_classify(p, mother, param, dt, scales, nrows, ncols, 1, codes.data());
+  if (rc) return rc;
+  return cwt_shard_codes(codes.data(), nrows, p->prec, double(p->N) / double(1 << 20), chunk_rows_of(p), world, first, count);
+}
+
 int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, int64_t* n_records) {
   if (!p || !n_records) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));

@@ -359,8 +359,19 @@ struct Fft {
     constexpr int LOGNS = 4 * S;
     const int k = j & ((1 << LOGNS) - 1);
     if constexpr (S > 0) {
+#if defined(CWT_LAB) && defined(CWT_TW_TABLE)
+      // experiment: the 15 powers w^m from the table (15 loads through the idle texture path) instead of a running product
+#pragma unroll
+      for (int m = 1; m < 16; ++m) {
+        const cplx<T> w = tw[(k * m) << (LOGL - LOGNS - 4)];
+        const T x = re[m], y = im[m];
+        re[m] = x * w.x - y * w.y;
+        im[m] = x * w.y + y * w.x;
+      }
+#else
       const cplx<T> w = stage_tw<T>(tw, k << (LOGL - LOGNS - 4));
       twiddle_chain<T, 16>(re, im, w.x, w.y);
+#endif
     }
     bfly16<T>(re, im);
     if constexpr (S == NFULL - 1 && REM == 0) return;

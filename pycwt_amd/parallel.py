@@ -15,6 +15,7 @@ sharding / collective logic under the gloo backend.
 """
 from __future__ import annotations
 
+import ctypes as C
 import functools
 
 import numpy as np
@@ -28,106 +29,46 @@ def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
     return np.arange(rank, nrows, world)
 
 
-# Cost model of one rank's step, microseconds at N = 2^20: a fixed part per kernel class that has at least one row
-# (launch ramp and tail; for the overlap-save classes the block spectra of that tile size) plus a per-row part.  Fitted
-# to the per-class launch durations of bench.py on BASELINE config 2 / 3 (round 3: `roofline.per_class` of
-# profiles/r03_bench_default.json, and the per-rank runs of profiles/r03_shards.txt).
-_COST = {
-    64: {"fwd": 28.0, "two_pass": (18.0, 9.8), "narrow_k2048": (8.0, 5.9), "ols": (27.0, 3.9), "ols_half": (23.0, 3.5),
-         "narrow": (5.0, 2.85), "narrow_t": 0.9},
-    32: {"fwd": 27.0, "two_pass": (14.0, 5.3), "narrow_k2048": (8.0, 5.4), "ols": (28.0, 2.3), "ols_half": (20.0, 1.9),
-         "narrow": (4.0, 1.75), "narrow_t": 0.55},
-}
+# The cost model and the search live in the C library (cwt_shard_codes / cwt_shard_cost / cwt_plan_balanced_shards, so that
+# a host in any language gets the same shards): a fixed part per kernel class present (launch ramp and tail, block spectra)
+# + a per-row part, fitted to the per-class launch durations of bench.py (profiles/r03_per_class.txt, r03_shards.txt).
+def _lib(lib=None):
+    return lib or _hip._default or _hip.load()
 
 
-def _shard_cost(labels, precision, nscale=1.0):
-    """Estimated step time of a rank that owns the rows with these class labels.  `nscale` = transform length / 2^20:
-    the per-row parts scale with it, the fixed parts (launch ramp and tail) do not."""
-    c = _COST[precision]
-    total, seen = 0.0, set()
-    n_two_pass = sum(1 for lab in labels if lab.startswith("two_pass"))
-    chunk = max(1, int(12 / nscale))      # rows per two-pass launch pair: the intermediate must fit the Infinity Cache
-    if n_two_pass > chunk:
-        total += c["two_pass"][0] * ((n_two_pass - 1) // chunk)
-    for lab in labels:
-        kind = lab.split("/")[0]
-        if kind.startswith("ols"):
-            kind = "ols_half" if lab.endswith("/half") else "ols"
-        elif kind == "single_wg":
-            kind = "narrow"
-        fixed, per = c[kind]
-        per *= nscale
-        if kind not in seen:
-            seen.add(kind)
-            total += fixed
-        total += per
-        if kind == "narrow" and "/K" in lab:             # longer transforms per residue, shorter store segments
-            k = int(lab.split("/K")[1].split("/")[0])
-            total += per * (0.25 if k >= 1024 else 0.13 if k >= 512 else 0.05 if k >= 32 else -0.05)
-            if "/t" in lab:
-                total += nscale * c["narrow_t"] * (int(lab.rsplit("/t", 1)[1]) - 1)
-    if seen - {"ols", "ols_half"}:
-        total += c["fwd"] * max(nscale, 0.5)   # some row needs the spectrum
-    return total
+def _chunk_rows(precision: int, nfft: int) -> int:
+    """Rows per two-pass launch pair of a default plan: the intermediate must fit 192 MiB (Infinity Cache)."""
+    return max(1, (192 << 20) // (int(nfft) * (16 if precision == 64 else 8)))
 
 
-def balanced_shards(labels, world: int, precision: int = 64, nfft: int = 1 << 20):
-    """See `_balanced_shards`; results are cached per (labels, world, precision, length): repeated transforms of one
-    scale grid (the normal use) pay the search once.  `nfft` = padded transform length (the cost table is fitted at 2^20;
-    per-row costs scale with the length, per-launch costs do not)."""
-    return [np.array(s) for s in _balanced_shards(tuple(labels), world, precision, float(nfft) / float(1 << 20))]
+def shard_cost(labels, precision: int = 64, nfft: int = 1 << 20, lib=None) -> float:
+    """The model's estimate (microseconds per step) for a rank that owns the rows with these class labels."""
+    codes = _hip.Plan.codes_of(labels)
+    arr = (C.c_int * max(len(codes), 1))(*codes)
+    out = C.c_double(0)
+    L = _lib(lib)
+    L.check(L.cwt_shard_cost(arr, len(codes), precision, float(nfft) / float(1 << 20), _chunk_rows(precision, nfft), C.byref(out)))
+    return out.value
+
+
+def balanced_shards(labels, world: int, precision: int = 64, nfft: int = 1 << 20, lib=None):
+    """Cuts the scale grid (rows in scale order, `labels` = their kernel classes from `Plan.classify`) into `world`
+    CONTIGUOUS shards of equal estimated cost (cwt_shard_codes).  Against interleaving (row j -> rank j mod G) a rank
+    then runs few kernel classes with many rows each instead of every class with a handful -- at 8 ranks the
+    interleaved share is 2 two-pass rows, 2 K = 2048 rows, 10 overlap-save rows ..., all launch-latency bound -- and
+    ranks whose rows are all overlap-save never need the forward FFT.  Returns a list of index arrays (possibly empty);
+    cached per (labels, world, precision, length)."""
+    return [np.array(s) for s in _balanced_shards(tuple(labels), world, precision, int(nfft), _lib(lib))]
 
 
 @functools.lru_cache(maxsize=64)
-def _balanced_shards(labels, world: int, precision: int = 64, nscale: float = 1.0):
-    """Cuts the scale grid (rows in scale order, `labels` = their kernel classes from `Plan.classify`) into `world`
-    CONTIGUOUS shards of equal estimated cost.  Against interleaving (row j -> rank j mod G) a rank then runs few
-    kernel classes with many rows each instead of every class with a handful -- at 8 ranks the interleaved share
-    is 2-3 two-pass rows, 2 K = 2048 rows, 9 overlap-save rows ..., all launch-latency bound -- and ranks whose rows
-    are all overlap-save never need the forward FFT.  Returns a list of index arrays (possibly empty)."""
-    n = len(labels)
-    if world <= 1 or n == 0:
-        return [np.arange(n)] + [np.arange(0)] * (world - 1)
-
-    def cuts_for(limit):
-        cuts, lo = [], 0
-        for _ in range(world):
-            hi = lo
-            # largest hi with cost(lo:hi) <= limit (cost is monotone in hi)
-            a, b = lo, n
-            while a < b:
-                m = (a + b + 1) // 2
-                if _shard_cost(labels[lo:m], precision, nscale) <= limit:
-                    a = m
-                else:
-                    b = m - 1
-            hi = max(a, lo + 1) if lo < n else lo
-            cuts.append((lo, min(hi, n)))
-            lo = min(hi, n)
-        return cuts if lo >= n else None
-
-    lo_t, hi_t = 0.0, _shard_cost(labels, precision, nscale)
-    for _ in range(40):
-        mid = 0.5 * (lo_t + hi_t)
-        if cuts_for(mid) is None:
-            lo_t = mid
-        else:
-            hi_t = mid
-    cuts = cuts_for(hi_t)
-    # The greedy fill leaves the slack in the last shard and may strand one or two rows of a kernel class in a shard
-    # (a one-row launch of the K = 2048 kernel costs 25 us): move every boundary by up to 4 rows where that lowers the
-    # larger of the two neighbouring shards.
-    bounds = [a for a, _ in cuts] + [n]
-    for _ in range(3):
-        for i in range(1, world):
-            lo, hi = bounds[i - 1], bounds[i + 1]
-            best, best_cost = bounds[i], None
-            for b in range(max(lo, bounds[i] - 4), min(hi, bounds[i] + 4) + 1):
-                cost = max(_shard_cost(labels[lo:b], precision, nscale), _shard_cost(labels[b:hi], precision, nscale))
-                if best_cost is None or cost < best_cost - 1e-9:
-                    best, best_cost = b, cost
-            bounds[i] = best
-    return [np.arange(bounds[i], bounds[i + 1]) for i in range(world)]
+def _balanced_shards(labels, world, precision, nfft, lib):
+    codes = _hip.Plan.codes_of(labels)
+    arr = (C.c_int * max(len(codes), 1))(*codes)
+    first, count = (C.c_int * world)(), (C.c_int * world)()
+    lib.check(lib.cwt_shard_codes(arr, len(codes), precision, float(nfft) / float(1 << 20), _chunk_rows(precision, nfft),
+                                  world, first, count))
+    return [np.arange(first[r], first[r] + count[r]) for r in range(world)]
 
 
 _engines: dict = {}       # default engines of cwt_sharded, one per (length, precision, device): keeps the row-table cache
@@ -236,7 +177,8 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     # balanced shards need the classification of the WHOLE grid: an engine sized for its own share cannot give it
     can_classify = hasattr(engine, "classify") and getattr(getattr(engine, "plan", None), "max_rows", sj.size) >= sj.size
     if partition == "balanced" and nbatch == 1 and world > 1 and can_classify:
-        mine = balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision, N)[rank]
+        mine = (engine.plan.balanced_shards(kind, param, dt, sj, n0, world)[rank] if hasattr(engine, "plan")
+                else balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision, N)[rank])
     else:
         mine = shard_rows(sj.size, world, rank)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)

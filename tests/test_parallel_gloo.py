@@ -208,13 +208,18 @@ def test_balanced_shards_cover_the_grid_and_even_out_the_cost(emu_library):
     labels = plan.classify(orc.MORLET, 6.0, 1.0, sj, N, True)
     assert len(labels) == len(sj) and any(l.startswith("ols") for l in labels)
     assert not any(l.startswith("ols") for l in plan.classify(orc.MORLET, 6.0, 1.0, sj, N, False))
+    assert _hip.Plan._labels(_hip.Plan.codes_of(labels)) == labels           # label <-> code round trip
+    by_plan = {w: plan.balanced_shards(orc.MORLET, 6.0, 1.0, sj, N, w) for w in (2, 8)}   # the C entry point a non-Python host uses
     plan.close()
+    for w, shards in by_plan.items():
+        assert all(np.array_equal(a, b) for a, b in zip(shards, parallel.balanced_shards(labels, w, 64, N, lib=emu_library)))
     for world in (1, 2, 3, 4, 8):
-        shards = parallel.balanced_shards(labels, world, 64)
+        shards = parallel.balanced_shards(labels, world, 64, N, lib=emu_library)
         assert len(shards) == world
         assert np.array_equal(np.concatenate(shards), np.arange(len(sj)))
-        cost = [parallel._shard_cost([labels[i] for i in s], 64) for s in shards]
-        inter = [parallel._shard_cost([labels[i] for i in range(r, len(sj), world)], 64) for r in range(world)]
+        cost = [parallel.shard_cost([labels[i] for i in s], 64, N, lib=emu_library) for s in shards]
+        inter = [parallel.shard_cost([labels[i] for i in range(r, len(sj), world)], 64, N, lib=emu_library)
+                 for r in range(world)]
         assert max(cost) <= max(inter) + 1e-9, (world, cost, inter)
         if world > 1:
             assert max(cost) - min(c for c in cost if c > 0) < 40.0, (world, cost)
