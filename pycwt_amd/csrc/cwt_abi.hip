@@ -177,6 +177,8 @@ struct cwt_plan {
   int big_terms = 6;       // ... and at K = 2048 (fp64, 16384-point workgroups; <= 8)
   int pass_a_small = 1;      // pass A on half-size workgroup tiles (4 per CU instead of 2): -5 % fp64, -8 % fp32
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
+  int narrow_mix = 0;      // launch order of the band-limited rows alternates light and heavy rows (default: on for
+                           // precision 64 -- measured -3.5 % on that kernel, -2 % on the step; +-0 / -2 % in fp32)
   int narrow_wave = 0;     // [lab] band-limited rows with K <= 128 on the barrier-free kernel (one transform per wavefront)
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
   int force_logk = 0;
@@ -657,6 +659,24 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
+  if (p->narrow_mix) {
+    // Launch order inside k_narrow_ct_all: the rows are sorted light (K = 16: store bound) to heavy (K = 1024 with three
+    // terms: the longest compute phase); consecutive rows share the CUs, so alternate the two ends of the list -- a CU's two
+    // tile slots then hold one store-heavy and one compute-heavy tile instead of two of a kind.  (Complex64: the rows
+    // that run on half-size tiles, K <= 512 with one term, stay a block of their own at the front.)
+    auto zigzag = [&](size_t lo, size_t hi) {
+      std::vector<RowDesc> tmp(narrow_rows.begin() + lo, narrow_rows.begin() + hi);
+      size_t a = 0, b = tmp.size();
+      for (size_t i = lo; i < hi; ++i) narrow_rows[i] = ((i - lo) & 1) ? tmp[--b] : tmp[a++];
+    };
+    size_t n0 = 0;
+    while (n0 < narrow_rows.size() && group_key(narrow_rows[n0]) < 100000) ++n0;        // class 0: k_narrow_ct_all
+    size_t nh = 0;
+    if (p->prec == 32 && p->narrow_small)
+      while (nh < n0 && narrow_rows[nh].logK <= 9 && narrow_rows[nh].nterms == 1) ++nh;
+    if (nh > 1) zigzag(0, nh);
+    if (n0 - nh > 1) zigzag(nh, n0);
+  }
   p->rt->table.clear();
   p->rt->narrow_groups.clear();
   p->rt->table.insert(p->rt->table.end(), small_rows.begin(), small_rows.end());
@@ -1495,13 +1515,14 @@ int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
   return CWT_OK;
 }
 
-// Side streams carry filler work (band-limited rows beside the two-pass chain): lowest priority, so that their
-// workgroups take the slots the chain leaves free (launch ramps and tails) instead of competing with it.
-// CWT_SIDE_PRIORITY=0 creates them at default priority (tuning).
+// Side streams (band-limited rows, overlap-save chain, K = 2048 rows beside the two-pass chain on the plan's stream) at
+// the default priority: all four queues are served alike.  Rounds 1-2 created them at the lowest priority (filler work
+// under the two-pass chain); at sustained clocks that measured +1 % on the fp64 step (1.005-1.007 against 0.993-0.998 ms,
+// three pairs) and +-0 in fp32.  CWT_SIDE_PRIORITY=low restores it (tuning).
 hipError_t create_side_stream(hipStream_t* s) {
   int least = 0, greatest = 0;
   const char* e = std::getenv("CWT_SIDE_PRIORITY");
-  if ((!e || std::atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+  if (e && std::string(e) == "low" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
   (void)hipGetLastError();
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -1573,6 +1594,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
 #endif
+  p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
     if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
@@ -1662,6 +1684,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
+  else if (k == "narrow_mix") p->narrow_mix = value != 0;
   else if (k == "narrow_wave") p->narrow_wave = value != 0;
   else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
