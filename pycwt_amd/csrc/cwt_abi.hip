@@ -2439,7 +2439,7 @@ namespace {
 // overlap-save classes the block spectra of that tile size) + a per-row part.  Fitted to the per-class launch durations of
 // bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt.
 struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term; };
-constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 8.0, 5.9, 27.0, 3.9, 23.0, 3.5, 5.0, 2.85, 0.9};
+constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.4, 8.0, 2.85, 0.9};
 constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55};
 
 // Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
