@@ -340,3 +340,23 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
         assert any(c.endswith("/half") for c in classes) == (opts["ols_small_max_halo"] > 0)
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
     assert per_row.max() < TOL[prec], (per_row.argmax(), classes[per_row.argmax()], per_row.max())
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_launch_order_of_the_band_limited_rows_does_not_change_a_bit(emu_library, prec):
+    """Option narrow_mix (default on in fp64): the band-limited rows are launched light / heavy alternating instead of sorted
+    by class; every row is computed by the same code either way."""
+    N = 1 << 16
+    x = np.random.default_rng(23).standard_normal(N - 9)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(x.size, 1.0, m, 80)
+    out = []
+    for mix in (0, 1):
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"narrow_mix": mix, "ols_min_logn": 15})
+        W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
+        assert plan.last_split()["narrow"] >= 30
+        plan.close()
+        out.append(W)
+    assert np.array_equal(out[0], out[1])
+    per_row, _ = row_errors(out[1], orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
+    assert per_row.max() < TOL[prec]
