@@ -91,7 +91,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
  *   "ols_big"      1 = rows with halo >= "ols_big_min_halo" (default 1536) and a block support <= 1/8 tile use blocks
- *                  of two workgroup tiles (default: 1 for precision 32, 0 for 64, where it measured no gain)
+ *                  of two workgroup tiles; 2 = also blocks of FOUR tiles for halos in ["ols_big4_min_halo" (2048),
+ *                  "ols_big4_max_halo" (8192)]: their block spectra are one 16384-point packed transform per block
+ *                  (default: 1 for precision 32, 0 for 64; 2 measured -1 ... +3 % depending on the thresholds: the rows
+ *                  gain what the extra block-spectra launch costs)
  *   "ols_small_max_halo" overlap-save rows with a halo up to this many samples (multiple of 64, default 512) run on
  *                  half-size workgroup tiles -- four block transforms in flight per CU instead of two; 0 = none
  *   "ols_fwd_real" [lab] 0 = block spectra of the overlap-save rows from a complex transform of the whole zero-imaginary block

@@ -199,6 +199,8 @@ struct cwt_plan {
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
   int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
+  int ols_big4_min_halo = 2048;  // ols_big = 2: rows with a halo from here on use blocks of 4P points (four workgroups per block)
+  int ols_big4_max_halo = 8192;  // ... up to this halo (a quarter of the block at most)
   int ols_max_halo = 0;    // largest halo H of such a row in samples; 0 = a quarter of the workgroup tile (L >= P/2)
   double ols_fwd_weight = 1.0;   // cost of one block spectrum in units of one row's block transform (class grouping)
   // Accuracy target of a row, max|dW| / max|W| against the exact transform (cwt_plan_set_tolerance; 0 = the precision's
@@ -240,7 +242,7 @@ struct cwt_plan {
       int logp = 13;                     // log2 of the workgroup tile
       OlsClasses cls;                    // halo classes of this group (wg_first / row_first relative to the group)
       long wgs = 0;                      // workgroups of its k_ols_ct launch
-      long fwd_blocks[2] = {0, 0};       // blocks of P points, blocks of 2P points (k_ols_fwd launches)
+      long fwd_blocks[3] = {0, 0, 0};    // blocks of P, 2P, 4P points (k_ols_fwd_r launches)
       int row_first = 0, nrows = 0;      // its rows inside [ols_first, ols_first + n_ols)
     };
     OlsGroup ols_grp[2];
@@ -515,6 +517,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
   const bool ols_big = ols_ok && p->ols_big && ols_logp == 13 && p->logN >= ols_logp + 3;   // blocks of 2P points
+  const bool ols_big4 = ols_big && p->ols_big >= 2 && p->logN >= ols_logp + 4;               // ... and of 4P points
   const double ols_ch = ols_ok ? time_halo_factor(mother, param, tol.halo) : 0.0;
   // "not clipped at Nyquist": the profile at the Nyquist bins is below this fraction of its peak (the jump there is what
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
@@ -584,7 +587,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       if (ols_ok && unclipped && rd.nband > 0) {
         const double s_samples = rd.a * double(N) / 6.283185307179586476925;
         const double hh = std::ceil(ols_ch * s_samples / 64.0) * 64.0;
-        if (hh <= double(ols_hmax) * (ols_big ? 2.0 : 1.0)) halo = std::max(64, int(hh));
+        const double cap = ols_big4 ? std::max(double(std::min(p->ols_big4_max_halo, 4 * ols_hmax)), 2.0 * ols_hmax)
+                                    : double(ols_hmax) * (ols_big ? 2.0 : 1.0);
+        if (hh <= cap) halo = std::max(64, int(hh));
       }
       RowDesc od = rd;
       if (halo) {
@@ -620,11 +625,17 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           describe(ols_logp_s, ols_logp_s, od);
           lb = ols_logp_s; grp = 0;
         } else {
-          if (ols_big && halo >= p->ols_big_min_halo) {
-            describe(ols_logp + 1, ols_logp, big);
-            big_fits = big.logK <= ols_logp - 3;
+          int big_lb = 0;
+          if (ols_big4 && halo >= p->ols_big4_min_halo) {       // blocks of 4P points: the stores stay >= 128-byte segments
+            describe(ols_logp + 2, ols_logp, big);             // while K <= P/8, as for 2P
+            if (big.logK <= ols_logp - 3) { big_fits = true; big_lb = ols_logp + 2; }
           }
-          if (big_fits) { od = big; lb = ols_logp + 1; }
+          if (!big_fits && ols_big && halo >= p->ols_big_min_halo && halo <= 2 * ols_hmax) {
+            big = rd;
+            describe(ols_logp + 1, ols_logp, big);
+            if (big.logK <= ols_logp - 3) { big_fits = true; big_lb = ols_logp + 1; }
+          }
+          if (big_fits) { od = big; lb = big_lb; }
           else if (halo <= ols_hmax) describe(ols_logp, ols_logp, od);
           else halo = 0;
         }
@@ -702,7 +713,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   for (int g = 0; g < 2; ++g) {
     auto& G = p->rt->ols_grp[g];
     G.logp = g == 0 ? (ols_logp_s ? ols_logp_s : ols_logp) : ols_logp;
-    G.cls.n = 0; G.wgs = 0; G.fwd_blocks[0] = G.fwd_blocks[1] = 0; G.row_first = G.nrows = 0;
+    G.cls.n = 0; G.wgs = 0; G.fwd_blocks[0] = G.fwd_blocks[1] = G.fwd_blocks[2] = 0; G.row_first = G.nrows = 0;
     for (int i = 0; i < OLS_MAX_CLASSES; ++i) G.cls.wg_first[i] = 0x7fffffff;
   }
   if (!ols_rows.empty()) {
@@ -717,7 +728,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       OlsClasses& oc = grp.cls;
       grp.row_first = row0;
       long wg = 0;
-      for (int lb = grp.logp; lb <= grp.logp + 1; ++lb) {
+      for (int lb = grp.logp; lb <= grp.logp + 2; ++lb) {
         int nr = 0;
         while (row0 + nr < int(ols_rows.size()) && ols_rows[row0 + nr].grp == g && ols_rows[row0 + nr].lb == lb) ++nr;
         if (!nr) continue;
@@ -727,7 +738,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           if (hv.empty() || hv.back() != ols_rows[i].h64) { hv.push_back(ols_rows[i].h64); cnt.push_back(0); }
           cnt.back()++;
         }
-        const int nd = int(hv.size()), KC = OLS_MAX_CLASSES / 2;
+        const int nd = int(hv.size()), KC = (lb == grp.logp || !ols_big4) ? OLS_MAX_CLASSES / 2 : OLS_MAX_CLASSES / 4;
         std::vector<int> pre(nd + 1, 0);
         for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
         auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
@@ -1173,11 +1184,13 @@ int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
 // 2^(LOGM + 1)) ...
 template <typename T, int LOGM>
 int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
+  static const bool once = (allow_big_lds(&k_ols_fwd_r<T, LOGM>), true);
+  (void)once;
   const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
   return timed_launch(p, KC_OLS_FWD, [&] {
     hipLaunchKernelGGL((k_ols_fwd_r<T, LOGM>), dim3(unsigned(blocks)), dim3(1 << (LOGM - 4)), lds, st,
                        static_cast<const T*>(x_dev), long(n0), p->logN, cls, static_cast<const cplx<T>*>(p->tw_all),
-                       static_cast<cplx<T>*>(p->xs));
+                       twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
   }, st);
 }
 template <typename T>
@@ -1190,7 +1203,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
     for (int g = 0; g < 2 && !rc; ++g) {
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows) continue;
-      for (int d = 0; d < 2 && !rc; ++d) {
+      for (int d = 0; d < 3 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
 #ifdef CWT_LAB
@@ -1200,6 +1213,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
           case 12: rc = launch_ols_fwd_r<T, 11>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 13: rc = launch_ols_fwd_r<T, 12>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 14: rc = launch_ols_fwd_r<T, 13>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
+          case 15: rc = launch_ols_fwd_r<T, 14>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           default: return fail(CWT_EINVAL, "overlap-save block length");
         }
       }
@@ -1713,7 +1727,9 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "sched") p->sched = int(value);
   else if (k == "ols") p->ols = value != 0;
   else if (k == "ols_side") p->ols_side = value != 0;
-  else if (k == "ols_big") p->ols_big = value != 0;
+  else if (k == "ols_big") { if (value < 0 || value > 2) return fail(CWT_EINVAL, "ols_big: 0, 1 (blocks of two tiles) or 2 (also of four)"); p->ols_big = int(value); }
+  else if (k == "ols_big4_max_halo") { if (value < 2048 || value > 8192 || (value & 63)) return fail(CWT_EINVAL, "ols_big4_max_halo: multiple of 64 in [2048, 8192]"); p->ols_big4_max_halo = int(value); }
+  else if (k == "ols_big4_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big4_min_halo in [64, 8192]"); p->ols_big4_min_halo = int(value); }
   else if (k == "ols_min_logn") { if (value < 15 || value > 24) return fail(CWT_EINVAL, "ols_min_logn in [15, 24]"); p->ols_min_logn = int(value); }
   else if (k == "ols_tile") { if (value != 8192 && value != 4096 && value != 2048 && value != 1024 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 1024, 2048, 4096, 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
   else if (k == "ols_fwd_real") p->ols_fwd_real = value != 0;

@@ -1182,7 +1182,7 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
 // through one extra pass of the exchange buffer.  Blocks of two workgroup tiles (P_b = 2P) are ONE M = P transform.
 template <typename T, int LOGM>
 __global__ void __launch_bounds__(1 << (LOGM - 4), 4)
-k_ols_fwd_r(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all,
+k_ols_fwd_r(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all, TwN<T> twn,
             cplx<T>* __restrict__ xs) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
@@ -1223,14 +1223,16 @@ k_ols_fwd_r(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cp
 #pragma unroll
   for (int e = 0; e < 16; ++e) mi[e] = lds[f.phys((M - f.j - e * NT) & (M - 1))];
   cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ((PB >> 1) + 8);
-  const cplx<T>* twb = tw_all + (PB - 2);                  // e^{2 pi i p / P_b}
+  // e^{2 pi i p / P_b}: from the table of length P_b where it exists (P_b <= 16384), else from the N-point tables
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int k = f.j + e * NT;
     // Z[k] = (re, -im), conj Z[M-k] = (mr, +mi)
     const T er = T(0.5) * (re[e] + mr[e]), ei = T(0.5) * (mi[e] - im[e]);          // E = (Z + conj Zm) / 2
     const T dr = T(0.5) * (re[e] - mr[e]), di = T(0.5) * (-im[e] - mi[e]);         // D = (Z - conj Zm) / 2,  O = D / i = (di, -dr)
-    const cplx<T> w = twb[k];                                                      // e^{+2 pi i k / P_b}; we need its conjugate
+    cplx<T> w;                                                                     // e^{+2 pi i k / P_b}; we need its conjugate
+    if constexpr (LOGB <= 14) w = (tw_all + (PB - 2))[k];
+    else w = twn(unsigned(k) << (logN - LOGB));
     const T orr = di, oi = -dr;
     out[k] = mk<T>(er + orr * w.x + oi * w.y, ei + oi * w.x - orr * w.y);          // E + conj(w) O
     if (k == 0) out[M] = mk<T>(er - orr, T(0));                                    // X[M] = Re Z[0] - Im Z[0]

@@ -319,6 +319,7 @@ def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
     (orc.MORLET, 6, 64, {"ols_big": 1, "ols_big_min_halo": 256}),   # fp64: double-length blocks are opt-in
     (orc.MORLET, 6, 64, {"ols_big": 0}),
     (orc.PAUL, 4, 32, {"ols_big_min_halo": 512}),
+    (orc.MORLET, 6, 64, {"ols_big": 2, "ols_big4_min_halo": 1024}),   # blocks of four tiles (one 16384-point packed block spectrum)
     (orc.MORLET, 6, 64, {"ols_small_max_halo": 0}),        # every row on the default tile
     (orc.DOG, 2, 32, {"ols_small_max_halo": 1024}),        # half-size tiles up to their limit (half the block is halo)
 ])
@@ -335,7 +336,10 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
     if opts == {"ols_big": 0}:     # default tiles: short halos on half-size tiles, the rest on the default tile, in ONE transform
         assert any(c.endswith("/half") for c in classes) and any(c.startswith("ols/") and not c.endswith("/half") for c in classes)
     big = [c for c in classes if c.startswith("ols2/")]
-    assert bool(big) == (opts.get("ols_big", int(prec == 32)) == 1), sorted(set(classes))
+    if opts.get("ols_big", 0) == 2:
+        assert any(c.startswith("ols4/") for c in classes), sorted(set(classes))
+    else:
+        assert bool(big) == (opts.get("ols_big", int(prec == 32)) == 1), sorted(set(classes))
     if "ols_small_max_halo" in opts:
         assert any(c.endswith("/half") for c in classes) == (opts["ols_small_max_halo"] > 0)
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
