@@ -36,6 +36,9 @@
 #ifndef CWT_LB_NARROW_F32
 #define CWT_LB_NARROW_F32 4
 #endif
+#ifndef CWT_LB_NARROW_F32_BIG
+#define CWT_LB_NARROW_F32_BIG 8   // the 16384-point (1024-thread) tiles of the fp32 K = 1024 rows: 64 VGPRs -> TWO workgroups per CU
+#endif                            // instead of one (2.50 -> 1.79 us per row); the K <= 512 rows on 8192-point tiles lose at 6 and 8
 #ifndef CWT_LB_OLS_F64
 #define CWT_LB_OLS_F64 4
 #endif
@@ -621,11 +624,17 @@ __device__ __forceinline__ void narrow_ct_body(const cplx<T>* __restrict__ xhat,
   }
 }
 
+// waves per SIMD the band-limited kernels are compiled for (see the CWT_LB_* defaults at the top)
+template <typename T, int LOGP>
+constexpr int narrow_waves_per_simd() {
+  return sizeof(T) == 8 ? CWT_LB_NARROW_F64 : LOGP >= 14 ? CWT_LB_NARROW_F32_BIG : CWT_LB_NARROW_F32;
+}
+
 // All band-limited rows of a transform in ONE launch: blockIdx.y walks the row table (sorted by
 // class), every workgroup branches once to the body specialised for its row's (K, terms).  One
 // launch instead of one per class removes ~10 kernel boundaries and partial last waves per transform.
 template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
+__global__ void __launch_bounds__(1 << (LOGP - 4), (narrow_waves_per_simd<T, LOGP>()))
 k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
                 long ncols) {
@@ -725,7 +734,7 @@ k_narrow_wave(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows
 // Band-limited rows with 5..16 aliased terms of K = 1024 bins (support up to 16384 bins): a kernel of their own so
 // that the common cases above keep their register allocation.
 template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
+__global__ void __launch_bounds__(1 << (LOGP - 4), (narrow_waves_per_simd<T, LOGP>()))
 k_narrow_ct_many(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
                  const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw,
                  long ncols) {

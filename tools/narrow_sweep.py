@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 from pycwt_amd import _hip
 ap = argparse.ArgumentParser(); ap.add_argument("--prec", type=int, default=64); ap.add_argument("--rows", type=int, default=48)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--bands", default="12,24,48,100,200,400,800,1000", help="support of the rows in bins, one group of rows per entry")
 args = ap.parse_args()
 opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
 N, rows, dt = 1 << 20, args.rows, 1.0
@@ -15,7 +16,7 @@ es = 8 if args.prec == 64 else 4
 x = np.random.default_rng(1).standard_normal(N).astype(np.float64 if es == 8 else np.float32)
 xd, xh, W = _hip.DeviceBuffer(N * es), _hip.DeviceBuffer(N * 2 * es), _hip.DeviceBuffer(rows * N * 2 * es)
 print(f"# prec {args.prec} opts {opts}: us per row, {rows} identical Morlet rows per scale (support ~ 3.04e6 / s bins)")
-for B in (12, 24, 48, 100, 200, 400, 800, 1000):
+for B in [int(b) for b in args.bands.split(",")]:
     s = 3.04e6 / B
     plan = _hip.Plan(N, args.prec, max_rows=rows, options=dict(opts, profile=1))
     xd.upload(plan, x)
