@@ -83,7 +83,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "narrow_mix"   1 = the launch order of the band-limited rows alternates the light (K = 16, store bound) and the heavy
  *                  end (K = 1024, several terms) of the list, so that a CU's two tile slots hold one of each (default 1 for
  *                  precision 64: -2 % of the step; 0 for 32, where it measured +-0)
- *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size)
+ *   "narrow_small" 0 = complex64 band-limited rows with K <= 512 on full-size tiles (default 1: half-size; the
+ *                  full-size instance is compiled for 64 VGPRs, which only its K = 1024 branches meet without spills:
+ *                  0 is correct but slower)
  *   "two_pass_logk" log2 of the row length K of the two-pass split N = R*K (0 = default: 1024 up to 2^21, 2048 above)
  *   "pass_b_small" [lab] 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
  *   "stamps"       [lab] n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
