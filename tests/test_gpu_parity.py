@@ -461,6 +461,33 @@ def test_stream_overlap_options_keep_parity_at_full_size(hip_library):
             assert np.array_equal(W, base), opts
 
 
+def test_fp32_band_limited_tile_variants_agree(hip_library):
+    """complex64 band-limited rows: K <= 512 on half-size tiles (default) or on the 16384-point instance (narrow_small = 0,
+    the one compiled for two workgroups per CU) -- the same arithmetic per output (bit-identical on the emulator; on the
+    device the two instances may contract multiply-adds differently, hence a few ulp); and both within the fp32 tolerance
+    of the oracle for every transform length K."""
+    N = 1 << 20
+    x = np.random.default_rng(78).standard_normal(N).astype(np.float32)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = 3.04e6 / np.array([12.0, 24, 48, 100, 200, 400, 800, 1000, 1500, 2500])     # K = 16 ... 1024, then two terms
+    out = {}
+    for small in (1, 0):
+        plan = _hip.Plan(N, 32, max_rows=16, options={"narrow_small": small})
+        xd, xh, Wd = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 8), _hip.DeviceBuffer(len(sj) * N * 8)
+        xd.upload(plan, x)
+        plan.transform(xd.ptr, N, orc.MORLET, 6.0, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+        out[small] = Wd.download(plan, (len(sj), N), np.complex64)
+        labels = plan.row_classes()
+        for b in (xd, xh, Wd):
+            b.free()
+        plan.close()
+        assert all(l.startswith("narrow/") for l in labels), labels
+    assert np.abs(out[0] - out[1]).max() <= 1e-6 * np.abs(out[1]).max()
+    ref = orc.cwt_rows(x.astype(np.float64), 1.0, sj, m)
+    per_row, _ = row_errors(out[1], ref)
+    assert per_row.max() < TOL[32], per_row
+
+
 def _download_rows(plan, buf, lo, cnt, ld, dtype):
     """Rows [lo, lo + cnt) of a device-resident row-major matrix with `ld` elements of `dtype` per row."""
     import ctypes as C
