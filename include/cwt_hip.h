@@ -189,6 +189,16 @@ int cwt_transform_rows_batch(cwt_plan* plan, const void* xhat_dev, int nbatch, i
                              int mother, double param, double dt, const double* scales_host,
                              int nrows, void* W_dev, int64_t ldw, int64_t ncols);
 
+/* The same batch from the SIGNALS (x_dev: nbatch real series of n0 samples, signal b at x_dev + b*x_ld): the forward
+ * transforms (spectra to xhat_dev, nbatch x nfft complex, as cwt_fft_rows writes them) and the rows in one call.  With
+ * the signals at hand the time-compact rows take the overlap-save form of cwt_transform (block spectra per signal, the
+ * filter tables shared by the signals); the batch counts towards "ols_min_logn" (nfft * nbatch >= 2^18 by default,
+ * nfft >= 4 tiles), so a batch of 2^16-point series replaces its two-pass rows (pycwt has no batched call: this is the
+ * loop `for x in signals: cwt(x, ...)` over wavelet.py:13-124 as one launch set).                                  */
+int cwt_transform_batch(cwt_plan* plan, const void* x_dev, int nbatch, int64_t x_ld, int64_t n0, int mother,
+                        double param, double dt, const double* scales_host, int nrows, void* xhat_dev, void* W_dev,
+                        int64_t ldw, int64_t ncols);
+
 /* Same transform for a mother wavelet that only exists as a Python object (the reference's
  * duck-typed protocol, mothers.py): the host evaluates psi_ft_bar = sqrt(s*w1*N)*conj(psi_ft(s*w)) as
  * wavelet.py:102-104 does and hands the filter bank over explicitly.

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import os
+import sys
 import threading
 
 import numpy as np
@@ -43,6 +44,8 @@ SYMBOLS = [
                                        C.c_int, _P, C.c_int64]),
     ("cwt_transform_rows_batch", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double,
                                            C.POINTER(C.c_double), C.c_int, _P, C.c_int64, C.c_int64]),
+    ("cwt_transform_batch", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double,
+                                      C.POINTER(C.c_double), C.c_int, _P, _P, C.c_int64, C.c_int64]),
     ("cwt_transform_rows_table", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P,
                                            C.c_int64, C.c_int64]),
     ("cwt_fft_rows", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
@@ -114,10 +117,27 @@ class Library:
 _default = None
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64 under the system's SONAMEs.  Whichever copy is
+    loaded first serves the whole process: with the system runtime first, torch (built against its own) finds no GPU --
+    `torch.cuda.is_available()` is False and tensors silently land on the CPU.  So when torch is installed, let it load
+    its runtime before libcwt_hip.so resolves the same SONAMEs (the library itself is torch-free; a C host is not
+    affected).  PYCWT_AMD_NO_TORCH_PRELOAD=1 skips this."""
+    if "torch" in sys.modules or os.environ.get("PYCWT_AMD_NO_TORCH_PRELOAD"):
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:       # a broken torch install must not take the transform down with it
+            pass
+
+
 def load() -> Library:
     """The product library (HIP, gfx950).  Raises if it is missing."""
     global _default
     if _default is None:
+        _one_hip_runtime()
         _default = Library(DEFAULT_LIBRARY)
     return _default
 
@@ -238,6 +258,14 @@ class Plan:
         self.lib.check(self.lib.cwt_transform_rows_batch(self.h, _P(xhat_dev), nbatch, xhat_ld, mother,
                                                          float(param), float(dt), _dptr(s), s.size, _P(W_dev),
                                                          ldw, ncols))
+
+    @_locked
+    def transform_batch(self, x_dev: int, nbatch: int, x_ld: int, n0: int, mother: int, param: float, dt: float,
+                        scales, xhat_dev: int, W_dev: int, ldw: int, ncols: int):
+        """Forward transforms + rows of a batch of signals (cwt_transform_batch): xhat_dev nbatch x nfft complex."""
+        s = np.ascontiguousarray(scales, dtype=np.float64)
+        self.lib.check(self.lib.cwt_transform_batch(self.h, _P(x_dev), nbatch, x_ld, n0, mother, float(param),
+                                                    float(dt), _dptr(s), s.size, _P(xhat_dev), _P(W_dev), ldw, ncols))
 
     @_locked
     def transform_rows_table(self, xhat_dev: int, table_dev: int, k_lo, nband, W_dev: int, ldw: int, ncols: int):

@@ -193,6 +193,7 @@ struct cwt_plan {
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
+  int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_tile = 8192;     // points per workgroup of those rows (fp32: 8192 or 16384)
   int ols_fwd_real = 1;    // block spectra from a complex transform of half the block length (real-input packing)
@@ -247,6 +248,8 @@ struct cwt_plan {
     };
     OlsGroup ols_grp[2];
     long ols_xs_elems = 0, ols_gt_elems = 0;
+    int ols_nbatch = 1;                  // signals of a batched call (cwt_transform_batch): block spectra per signal,
+    long ols_xs_sig = 0;                 // ols_xs_sig elements apart; the rows carry their signal's offset in spec_off
     void* gt_dev = nullptr;              // filter tables of the overlap-save rows, written when the table is built
     size_t gt_bytes = 0;
     RowDesc* rows_dev = nullptr;
@@ -512,8 +515,18 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : p->ols_tile == 4096 ? 12 : p->ols_tile == 2048 ? 11 : p->ols_tile == 1024 ? 10 : 13;
   // half-size tiles for short halos (only beside the default 8192-point tile)
   const int ols_logp_s = (p->ols_small_max_halo > 0 && ols_logp == 13) ? 12 : 0;
-  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && p->logN >= std::max(p->ols_min_logn, ols_logp + 2) &&
-                      mother != MOTHER_TABLE && spec_ld == 0 && rows_per_signal == 0 && !use_small;
+  // a batch of signals (cwt_transform_batch: rows_per_signal > 0 with the signals at hand) has nbatch times the blocks
+  // of one signal to fill the GPU with, so the form pays from shorter transforms: the threshold counts the batch
+  const int ols_nbatch = (rows_per_signal > 0 && ols_ncols > 0) ? std::max(1, nrows / rows_per_signal) : 1;
+#ifdef CWT_LAB
+  const bool ols_batch_ok = p->ols_fwd_real != 0;      // the lab's complex block transform has no batch form
+#else
+  const bool ols_batch_ok = true;
+#endif
+  const bool ols_layout = rows_per_signal > 0 ? (ols_batch_ok && ols_ncols > 0 && nrows % rows_per_signal == 0) : spec_ld == 0;
+  const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) &&
+                      p->logN + ilog2(ols_nbatch) >= p->ols_min_logn && p->logN >= ols_logp + 2 &&
+                      mother != MOTHER_TABLE && ols_layout && !use_small;
   const int ols_P = 1 << ols_logp;
   const int ols_hmax = p->ols_max_halo > 0 ? std::min(p->ols_max_halo, ols_P / 4) : ols_P / 4;
   const bool ols_big = ols_ok && p->ols_big && ols_logp == 13 && p->logN >= ols_logp + 3;   // blocks of 2P points
@@ -718,8 +731,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   }
   if (!ols_rows.empty()) {
     // by tile group, then block length, then halo
-    std::stable_sort(ols_rows.begin(), ols_rows.end(), [](const OlsRow& x, const OlsRow& y) {
-      return x.grp != y.grp ? x.grp < y.grp : x.lb != y.lb ? x.lb < y.lb : x.h64 < y.h64;
+    // (batch: then scale by scale, the signals of a scale in order -- k_ols_ct indexes a class's rows that way)
+    const int rps = rows_per_signal > 0 ? rows_per_signal : 1 << 30;
+    std::stable_sort(ols_rows.begin(), ols_rows.end(), [rps](const OlsRow& x, const OlsRow& y) {
+      if (x.grp != y.grp) return x.grp < y.grp;
+      if (x.lb != y.lb) return x.lb < y.lb;
+      if (x.h64 != y.h64) return x.h64 < y.h64;
+      return x.rd.out_row % rps < y.rd.out_row % rps;       // stable: equal scales stay in signal order
     });
     long xs = 0;
     int row0 = 0;                                                  // index into ols_rows
@@ -742,7 +760,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         std::vector<int> pre(nd + 1, 0);
         for (int i = 0; i < nd; ++i) pre[i + 1] = pre[i] + cnt[i];
         auto cost = [&](int i, int j) {                             // distinct halos i..j-1 as one class
-          return (double(pre[j] - pre[i]) + p->ols_fwd_weight) * double(Pb) / double(Pb - 128 * hv[j - 1]);
+          return (double(pre[j] - pre[i]) + p->ols_fwd_weight * ols_nbatch) * double(Pb) / double(Pb - 128 * hv[j - 1]);
         };
         const double inf = 1e300;
         std::vector<std::vector<double>> dp(KC + 1, std::vector<double>(nd + 1, inf));
@@ -765,14 +783,16 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           OlsClass& k = oc.c[oc.n++];
           k.halo = H;
           k.logb = lb;
-          k.pad_ = 0;
+          k.nsig = ols_nbatch;
           k.nblocks = int((ols_ncols + L - 1) / L);
           k.nrows = pre[hi_d] - pre[lo_d];
           k.row_first = row0 - grp.row_first + pre[lo_d];
           k.wg_first = int(wg);
           k.blk_first = int(blk);
           k.xs_off = xs;
-          wg += long((k.nblocks + 7) / 8) * 8 * k.nrows * G;
+          // the 8 XCDs share the (signal, block) pairs: nblocks alone can be as few as 17 (N = 2^16), which would leave
+          // one XCD with 3 blocks and seven with 2 + an idle pass (measured: +40 % on that kernel)
+          wg += ((long(k.nblocks) * ols_nbatch + 7) / 8) * 8 * (k.nrows / ols_nbatch) * G;
           blk += k.nblocks;
           xs += long(k.nblocks) * stride;
           lo_d = hi_d;
@@ -785,15 +805,28 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       for (int i = 0; i < OLS_MAX_CLASSES; ++i) oc.wg_first[i] = i < oc.n ? oc.c[i].wg_first : 0x7fffffff;
     }
     long gt_off = 0;                                            // filter tables: 2^logK entries per row (k_ols_gtab)
+    // batch: the table depends on the scale only (one per scale, shared by the signals); the block spectra are per
+    // signal, xs elements apart -- an overlap-save row reads its spectra at xs_dev + spec_off + class offset
+    std::vector<long> tab_of_scale(rows_per_signal > 0 ? rows_per_signal : 0, -1);
     for (auto& r : ols_rows) {
       r.rd.nterms = 1 << (r.lb - p->rt->ols_grp[r.grp].logp);   // nterms = workgroups per block
-      r.rd.tab_off = gt_off;
-      gt_off += 1L << r.rd.logK;
+      if (rows_per_signal > 0) {
+        long& t = tab_of_scale[r.rd.out_row % rows_per_signal];
+        if (t < 0) { t = gt_off; gt_off += 1L << r.rd.logK; }
+        r.rd.tab_off = t;
+        r.rd.spec_off = long(r.rd.out_row / rows_per_signal) * xs;
+      } else {
+        r.rd.tab_off = gt_off;
+        gt_off += 1L << r.rd.logK;
+        r.rd.spec_off = 0;
+      }
       p->rt->table.push_back(r.rd);
     }
     p->rt->ols_gt_elems = gt_off;
-    p->rt->ols_xs_elems = xs;
+    p->rt->ols_xs_sig = xs;
+    p->rt->ols_xs_elems = xs * ols_nbatch;
   }
+  p->rt->ols_nbatch = ols_nbatch;
   return CWT_OK;
 }
 
@@ -1188,9 +1221,10 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
   (void)once;
   const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
   return timed_launch(p, KC_OLS_FWD, [&] {
-    hipLaunchKernelGGL((k_ols_fwd_r<T, LOGM>), dim3(unsigned(blocks)), dim3(1 << (LOGM - 4)), lds, st,
-                       static_cast<const T*>(x_dev), long(n0), p->logN, cls, static_cast<const cplx<T>*>(p->tw_all),
-                       twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
+    hipLaunchKernelGGL((k_ols_fwd_r<T, LOGM>), dim3(unsigned(blocks), unsigned(p->rt->ols_nbatch)), dim3(1 << (LOGM - 4)),
+                       lds, st, static_cast<const T*>(x_dev), long(n0), p->logN, cls,
+                       static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), static_cast<cplx<T>*>(p->xs),
+                       long(p->ols_x_ld), p->rt->ols_xs_sig);
   }, st);
 }
 template <typename T>
@@ -2005,6 +2039,53 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   mo.kind = mother; mo.m = int(std::lround(param)); mo.p = param; mo.table = nullptr;
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols)
                        : rows_impl<float>(p, xhat_dev, mo, total, W_dev, ldw, ncols);
+}
+
+int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld, int64_t n0, int mother,
+                        double param, double dt, const double* scales, int nrows, void* xhat_dev, void* W_dev,
+                        int64_t ldw, int64_t ncols) {
+  if (!p || !x_dev || !scales || !xhat_dev || !W_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (nbatch < 1 || nrows < 1 || int64_t(nbatch) * nrows > p->max_rows)
+    return fail(CWT_EINVAL, "need nbatch*nrows <= max_rows");
+  if (n0 < 1 || n0 > p->N || x_ld < n0) return fail(CWT_EINVAL, "need 1 <= n0 <= nfft and x_ld >= n0");
+  if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
+  if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
+  HIPCHECK(hipSetDevice(p->device));
+  const int total = nbatch * nrows;
+  const std::vector<double> key = call_key(3, {double(mother), param, dt, double(nbatch), double(nrows), double(ncols)},
+                                           {{scales, nrows}});
+  if (!select_table(p, key)) {
+    double cre, cim;
+    int rc = mother_constant(mother, param, &cre, &cim);
+    if (rc) return rc;
+    const double w1 = 2.0 * 3.14159265358979323846 * (1.0 / (double(p->N) * dt));
+    std::vector<double> a(total), ar(total), ai(total);
+    for (int j = 0; j < total; ++j) {
+      const double s = scales[j % nrows];
+      if (!(s > 0) || !std::isfinite(s)) return fail(CWT_EINVAL, "scales must be positive and finite");
+      a[j] = s * w1;
+      const double norm = std::sqrt(s * w1 * double(p->N));
+      ar[j] = norm * cre;
+      ai[j] = norm * cim;
+    }
+    // as cwt_transform_rows_batch, with the signals at hand: time-compact rows may take the overlap-save form
+    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), p->N, total, nullptr, nullptr, nrows, -1, ncols);
+    if (!rc) rc = upload_row_table(p, key);
+    if (!rc && p->rt->n_ols)
+      rc = p->prec == 64 ? fill_ols_tables<double>(p, mother_of(mother, param)) : fill_ols_tables<float>(p, mother_of(mother, param));
+    if (rc) { p->rt->key.clear(); return rc; }
+  }
+  set_split(p);
+  const Mother mo = mother_of(mother, param);
+  int rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev)
+                         : fft_rows_impl<float, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev);
+  if (rc) return rc;
+  p->ols_launched = 0;
+  p->ols_x_ld = x_ld;
+  rc = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0)
+                     : rows_impl<float>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0);
+  p->ols_x_ld = 0;
+  return rc;
 }
 
 int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* table_dev, const int* k_lo,

@@ -1057,7 +1057,7 @@ struct OlsClass {
   int row_first;   // their first entry in the row table passed to k_ols_ct
   int halo;        // H (multiple of 64)
   int logb;        // log2 of the block length P_b >= P (workgroup tile): P_b / P workgroups share one block transform
-  int pad_;
+  int nsig;        // signals of a batched call (1 otherwise): nrows = nsig x rows per signal, scale by scale
   long xs_off;     // element offset of this class's block spectra (nblocks x (P_b/2 + 8) complex)
 };
 constexpr int OLS_MAX_CLASSES = 16;
@@ -1192,9 +1192,11 @@ k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx
 template <typename T, int LOGM>
 __global__ void __launch_bounds__(1 << (LOGM - 4), 4)
 k_ols_fwd_r(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all, TwN<T> twn,
-            cplx<T>* __restrict__ xs) {
+            cplx<T>* __restrict__ xs, long x_ld, long xs_sig) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
+  x += long(blockIdx.y) * x_ld;                             // batched call: blockIdx.y = signal
+  xs += long(blockIdx.y) * xs_sig;
   constexpr int M = 1 << LOGM, NT = M >> 4, LOGB = LOGM + 1, PB = 1 << LOGB;
   using F = ct::Fft<T, LOGM, 0, false>;
   const int wg = int(blockIdx.x);
@@ -1371,12 +1373,15 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
   const unsigned local = blockIdx.x - unsigned(oc.wg_first);
   const int logx = oc.logb - LOGP;
   const unsigned g = (local >> 3) & ((1u << logx) - 1u);      // which part of the block's residues
-  const unsigned seq = local >> (3 + logx), nr = unsigned(oc.nrows);
-  const unsigned blk = (seq / nr) * 8u + (local & 7u);
-  if (blk >= unsigned(oc.nblocks)) return;
-  const RowDesc rd = rows[oc.row_first + int(seq % nr)];
+  // (signal, block) pairs vb = signal * nblocks + block: XCD (workgroup id & 7) takes every 8th pair and walks the
+  // nrs rows of that signal's class back to back; the class's rows are stored scale by scale, nsig signals each
+  const unsigned seq = local >> (3 + logx), nsig = unsigned(oc.nsig), nrs = unsigned(oc.nrows) / nsig;
+  const unsigned vb = (seq / nrs) * 8u + (local & 7u);
+  if (vb >= unsigned(oc.nblocks) * nsig) return;
+  const unsigned sig = vb / unsigned(oc.nblocks), blk = vb - sig * unsigned(oc.nblocks);
+  const RowDesc rd = rows[oc.row_first + int((seq % nrs) * nsig + sig)];
   const int H = oc.halo, L = (P << logx) - 2 * H;
-  const cplx<T>* xb = xs + oc.xs_off + long(blk) * ((P << logx) / 2 + 8);
+  const cplx<T>* xb = xs + rd.spec_off + oc.xs_off + long(blk) * ((P << logx) / 2 + 8);   // spec_off: the row's signal (batch)
   const long col0 = long(blk) * L;
   const long left = ncols - col0;
   const int nlim = left < L ? int(left) : L;

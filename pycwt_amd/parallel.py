@@ -80,6 +80,11 @@ class HipEngine:
     def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int, on_torch_stream: bool = True):
         import torch
         self.torch = torch
+        if not on_torch_stream and _hip.load().backend().startswith("hip"):
+            # tensors that live on the host would hand host pointers to the kernels: a GPU memory fault, not an error
+            # (on_torch_stream=False is for the test suite's CPU emulation of the library)
+            raise RuntimeError("HipEngine needs tensors on a GPU and torch sees none (torch.cuda.is_available() is False: "
+                               "was another HIP runtime loaded before torch was imported?)")
         self.plan = _hip.Plan(nfft, precision, max_rows=max_rows, device=device_index)
         if on_torch_stream:               # tensors that live on a GPU: queue behind torch's work on its stream
             self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
@@ -105,9 +110,9 @@ class HipEngine:
         if x.dim() == 1:
             self.plan.transform(x.data_ptr(), n0, kind, param, dt, sj, None if xhat is None else xhat.data_ptr(),
                                 W.data_ptr(), W.shape[-1], ncols)
-        else:
-            self.forward(x, n0, xhat)
-            self.rows(xhat, kind, param, dt, sj, W, ncols)
+        else:                                             # a batch: cwt_transform_batch (spectra to xhat, required)
+            self.plan.transform_batch(x.data_ptr(), x.shape[0], x.shape[1], n0, kind, param, dt, sj, xhat.data_ptr(),
+                                      W.data_ptr(), W.shape[-1], ncols)
 
     def classify(self, kind, param, dt, sj, ncols):
         return self.plan.classify(kind, param, dt, sj, ncols, True)
@@ -182,9 +187,10 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     else:
         mine = shard_rows(sj.size, world, rank)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
-    if hasattr(engine, "transform") and nbatch == 1:
-        if mine.size:                                     # the spectrum stays inside the library
-            engine.transform(x, n0, None, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
+    if hasattr(engine, "transform"):
+        if mine.size:                                     # one signal: the spectrum stays inside the library
+            xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device) if nbatch > 1 else None
+            engine.transform(x, n0, xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)
     else:
         xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device)
         engine.forward(x, n0, xhat)

@@ -392,9 +392,16 @@ def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
         for b0 in range(0, nb, slab):
             cnt = min(slab, nb - b0)
             with plan.lock:
-                xd.upload(plan, np.ascontiguousarray(X[b0:b0 + cnt], dtype=plan.real))
-                plan.fft_rows(xd.ptr, False, cnt, n0, n0, xh.ptr)
-                plan.transform_rows_batch(xh.ptr, cnt, N, kind, param, dt, sj, Wd.ptr, n0, n0)
+                xs = np.ascontiguousarray(X[b0:b0 + cnt], dtype=plan.real)
+                xd.upload(plan, xs)
+                if np.isfinite(xs).all():
+                    # with the signals at hand the time-compact rows take the overlap-save form (cwt_transform_batch)
+                    plan.transform_batch(xd.ptr, cnt, n0, n0, kind, param, dt, sj, xh.ptr, Wd.ptr, n0, n0)
+                else:
+                    # a non-finite sample makes every coefficient of ITS signal NaN in the reference (the FFT spreads
+                    # it, wavelet.py:91): rows from the spectra alone do the same, block-wise rows would not
+                    plan.fft_rows(xd.ptr, False, cnt, n0, n0, xh.ptr)
+                    plan.transform_rows_batch(xh.ptr, cnt, N, kind, param, dt, sj, Wd.ptr, n0, n0)
                 W[b0:b0 + cnt] = Wd.download(plan, (cnt, rows, n0), plan.cplx)
                 xhat[b0:b0 + cnt] = xh.download(plan, (cnt, N), plan.cplx)
     finally:

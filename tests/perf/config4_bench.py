@@ -19,15 +19,20 @@ W = torch.empty(slab, rows, N, dtype=torch.complex128, device=dev)
 plan = _hip.Plan(N, 64, max_rows=slab * rows)
 plan.set_stream(torch.cuda.current_stream().cuda_stream)
 
-def run():
+def run_spectra():                                    # rounds 1-2: spectra first, then the rows from the spectra alone
     for b0 in range(0, nb_total, slab):
         plan.fft_rows(X[b0:b0 + slab].data_ptr(), False, slab, N, N, xh.data_ptr())
         plan.transform_rows_batch(xh.data_ptr(), slab, N, 0, 6.0, 1.0, sj, W.data_ptr(), N, N)
 
-run(); torch.cuda.synchronize()
-t = time.perf_counter(); run(); torch.cuda.synchronize(); el = time.perf_counter() - t
-print(f"config 4 on 1 GPU: {nb_total} x 2^16 x {rows}: {el*1e3:.1f} ms -> {nb_total*N*rows/el/1e9:.1f} GSamples*scales/s "
-      f"(split per slab {plan.last_split()})")
+def run():                                            # cwt_transform_batch: with the signals, time-compact rows go overlap-save
+    for b0 in range(0, nb_total, slab):
+        plan.transform_batch(X[b0:b0 + slab].data_ptr(), slab, N, N, 0, 6.0, 1.0, sj, xh.data_ptr(), W.data_ptr(), N, N)
+
+for name, f in (("from the spectra (cwt_fft_rows + cwt_transform_rows_batch)", run_spectra), ("cwt_transform_batch", run)):
+    f(); f(); torch.cuda.synchronize()                # second pass: the clock is up (tools/clock_ramp.py)
+    t = time.perf_counter(); f(); torch.cuda.synchronize(); el = time.perf_counter() - t
+    print(f"config 4 on 1 GPU, {name}: {nb_total} x 2^16 x {rows}: {el*1e3:.1f} ms -> {nb_total*N*rows/el/1e9:.1f} "
+          f"GSamples*scales/s (split per slab {plan.last_split()})")
 # parity: last slab holds signals 896..1023
 sel = [0, 40, 90, 127]
 for b in (0, 77, 127):

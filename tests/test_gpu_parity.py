@@ -362,7 +362,7 @@ def test_config4_shape_batch_of_signals(hip_library):
         assert per_row.max() < TOL[64]
     W1 = pycwt_amd.cwt(X[2], 1.0, dj, s0, rows - 1, "morlet")[0]
     per_row, _ = row_errors(Wb[2], W1)
-    assert per_row.max() < 1e-13
+    assert per_row.max() < TOL[64]          # the batch takes the overlap-save form for its time-compact rows, one signal of 2^16 does not
     Wl, mine, sj2, _, _ = parallel.cwt_sharded(X, 1.0, dj, s0, rows - 1, "morlet")
     assert tuple(Wl.shape) == (nb, rows, n0)
     assert np.abs(Wl[3].cpu().numpy() - Wb[3]).max() == 0
@@ -546,8 +546,8 @@ def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, 
 
 def test_config4_full_batch_sampled_pairs(hip_library):
     """BASELINE config 4 at full size on one GPU: 1024 signals x N = 2^16 x 128 Morlet scales through ONE batched
-    launch set (cwt_fft_rows + cwt_transform_rows_batch, 137 GB of W device resident), checked against the oracle
-    on sampled (signal, scale) pairs that cover every kernel class of the row table."""
+    launch set (cwt_transform_batch: forward transforms, block spectra per signal, rows; 137 GB of W device resident),
+    checked against the oracle on sampled (signal, scale) pairs that cover every kernel class of the row table."""
     nb, N, rows = 1024, 1 << 16, 128
     m = orc.Mother(orc.MORLET, 6)
     s0 = 2 / m.flambda()
@@ -557,11 +557,14 @@ def test_config4_full_batch_sampled_pairs(hip_library):
     xd, xh = _hip.DeviceBuffer(X.nbytes), _hip.DeviceBuffer(nb * N * 16)
     Wd = _hip.DeviceBuffer(nb * rows * N * 16)
     xd.upload(plan, X)
-    plan.fft_rows(xd.ptr, False, nb, N, N, xh.ptr)
-    plan.transform_rows_batch(xh.ptr, nb, N, orc.MORLET, 6.0, 1.0, sj, Wd.ptr, N, N)
+    plan.transform_batch(xd.ptr, nb, N, N, orc.MORLET, 6.0, 1.0, sj, xh.ptr, Wd.ptr, N, N)
     plan.sync()
     classes = plan.row_classes()
     assert len(classes) == nb * rows
+    assert any(c.startswith("ols") for c in classes) and any(c.startswith("two_pass") for c in classes)
+    xhat0 = _download_rows(plan, xh, nb - 1, 1, N, np.complex128)[0]
+    ref0 = np.fft.fft(X[nb - 1])
+    assert np.abs(xhat0 - ref0).max() < 1e-12 * np.abs(ref0).max()
     rng = np.random.default_rng(7)
     pairs = {(0, 0), (nb - 1, rows - 1), (nb - 1, 0), (0, rows - 1)}
     for c in sorted(set(classes)):                       # two random pairs of every kernel class

@@ -364,3 +364,56 @@ def test_launch_order_of_the_band_limited_rows_does_not_change_a_bit(emu_library
     assert np.array_equal(out[0], out[1])
     per_row, _ = row_errors(out[1], orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
     assert per_row.max() < TOL[prec]
+
+
+@pytest.mark.parametrize("kind,param,prec,logn,nb,rows,n0_off,opts", [
+    (orc.MORLET, 6, 64, 16, 4, 24, 0, None),
+    (orc.DOG, 2, 32, 15, 8, 16, 0, None),
+    (orc.MORLET, 6, 64, 15, 8, 40, 777, None),              # padded signals; scales that share a halo class and a halo
+    (orc.DOG, 2, 64, 15, 9, 20, 5, {"ols_small_max_halo": 0}),
+    (orc.MORLET, 6, 64, 16, 5, 18, 0, {"ols_big": 2, "ols_big4_min_halo": 1024}),
+])
+def test_batch_of_signals_takes_the_overlap_save_form(emu_library, kind, param, prec, logn, nb, rows, n0_off, opts):
+    """cwt_transform_batch: forward transforms + rows of a batch from the SIGNALS.  The batch counts towards the length
+    threshold of the overlap-save form, the block spectra are per signal, the filter tables per scale; every (signal,
+    scale) pair against the oracle, the spectra against numpy, and against the rows computed from the spectra alone."""
+    N = 1 << logn
+    n0 = N - n0_off
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    es = 8 if prec == 64 else 4
+    X = np.random.default_rng(5).standard_normal((nb, n0)).astype(real)
+    m = orc.Mother(kind, param)
+    sj = grid(N, 1.0, m, rows)
+    nr = len(sj)
+    plan = _hip.Plan(N, prec, max_rows=nb * nr, lib=emu_library, options=opts)
+    xd = _hip.DeviceBuffer(X.nbytes, lib=emu_library)
+    xh = _hip.DeviceBuffer(nb * N * 2 * es, lib=emu_library)
+    Wd = _hip.DeviceBuffer(nb * nr * n0 * 2 * es, lib=emu_library)
+    xd.upload(plan, X)
+    plan.transform_batch(xd.ptr, nb, n0, n0, kind, param, 1.0, sj, xh.ptr, Wd.ptr, n0, n0)
+    got = Wd.download(plan, (nb, nr, n0), cplx)
+    labels = plan.row_classes()
+    assert len(labels) == nb * nr and labels[:nr] == labels[-nr:]            # every signal: the same classes
+    assert sum(l.startswith("ols") for l in labels[:nr]) >= 3, labels[:nr]
+    xg = xh.download(plan, (nb, N), cplx)
+    xs = np.fft.fft(X.astype(np.float64), n=N, axis=1)
+    assert np.abs(xg - xs).max() < TOL[prec] * np.abs(xs).max()
+    for b in range(nb):
+        ref = orc.cwt_rows(X[b].astype(np.float64), 1.0, sj, m, N=N)[:, :n0]
+        per_row, _ = row_errors(got[b], ref)
+        assert per_row.max() < TOL[prec], (b, per_row.argmax(), per_row.max(), labels[per_row.argmax()])
+    # the same rows from the spectra alone (no overlap-save rows there)
+    plan.transform_rows_batch(xh.ptr, nb, N, kind, param, 1.0, sj, Wd.ptr, n0, n0)
+    assert not any(l.startswith("ols") for l in plan.row_classes())
+    per_row, _ = row_errors(Wd.download(plan, (nb * nr, n0), cplx), got.reshape(nb * nr, n0))
+    assert per_row.max() < TOL[prec]
+    for b in (xd, xh, Wd):
+        b.free()
+    plan.close()
+    # argument checks
+    plan = _hip.Plan(N, prec, max_rows=nr, lib=emu_library)
+    with pytest.raises(_hip.HipError):
+        plan.transform_batch(1, 2, n0, n0, kind, param, 1.0, sj, 1, 1, n0, n0)            # nbatch * nrows > max_rows
+    with pytest.raises(_hip.HipError):
+        plan.transform_batch(1, 1, n0 - 1, n0, kind, param, 1.0, sj, 1, 1, n0, n0)        # x_ld < n0
+    plan.close()
