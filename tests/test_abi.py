@@ -45,3 +45,18 @@ def test_argument_validation_without_gpu(emu_library):
     assert lib.cwt_plan_set_option(h, b"lmax", 100) < 0
     assert lib.cwt_forward_fft(h, None, 10, None) < 0
     assert lib.cwt_plan_destroy(h) == 0
+
+
+def test_torch_runtime_is_loaded_before_the_library():
+    """PyTorch-ROCm wheels bundle their own HIP runtime under the system's SONAMEs; the one loaded first serves the
+    process, and with the system's first torch sees no GPU.  `_hip.load()` therefore imports torch (if installed)
+    before it opens libcwt_hip.so; PYCWT_AMD_NO_TORCH_PRELOAD=1 skips that."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from pycwt_amd import _hip; assert 'torch' not in sys.modules; "
+            "_hip._one_hip_runtime(); print('torch' in sys.modules)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "True"
+    env = dict(os.environ, PYCWT_AMD_NO_TORCH_PRELOAD="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.strip()
+    assert out == "False"

@@ -225,6 +225,13 @@ def test_sharded_api_single_rank_matches_cwt(hip_library):
     np.testing.assert_allclose(iw, pycwt_amd.icwt(ref[0], ref[1], 0.5, 0.25, "dog"), rtol=1e-11, atol=1e-12)
 
 
+def test_hip_engine_refuses_host_tensors(hip_library):
+    """Tensors on the host would hand host pointers to the kernels (a GPU memory fault, not an error)."""
+    from pycwt_amd import parallel
+    with pytest.raises(RuntimeError, match="tensors on a GPU"):
+        parallel.HipEngine(4096, 64, 8, 0, on_torch_stream=False)
+
+
 @pytest.mark.parametrize("logn,prec,rows", [(21, 64, 6), (22, 64, 5), (23, 32, 4), (24, 32, 3), (24, 64, 2)])
 def test_long_series_up_to_the_plan_limit(hip_library, logn, prec, rows):
     """N = 2^21 .. 2^24 (the two-pass limit lmax^2): column FFTs of 2048..4096 points, generic engine."""
