@@ -117,3 +117,56 @@ def test_random_overlap_save_rows_match_oracle(emu_library, case):
     err = np.abs(W - ref).max(axis=1)
     scale = np.abs(ref).max(axis=1)
     assert (err <= tol * scale).all(), (opts, split, [(c, e / s) for c, e, s in zip(classes, err, scale)])
+
+
+@st.composite
+def batch_cases(draw):
+    """Batches of signals through cwt_transform_batch: lengths around the threshold of the overlap-save form (which counts
+    the batch), ragged signal length and leading dimension, unsorted / repeated scales, the block and tile options."""
+    logn = draw(st.integers(13, 16))
+    N = 1 << logn
+    n0 = draw(st.integers(N // 2 + 1, N))
+    x_ld = n0 + draw(st.sampled_from([0, 0, 3, 64]))
+    nb = draw(st.integers(1, 9))
+    kind, param = draw(st.sampled_from([(orc.MORLET, 6), (orc.MORLET, 9.0), (orc.DOG, 2), (orc.DOG, 1), (orc.PAUL, 4)]))
+    prec = 32 if kind == orc.PAUL else draw(st.sampled_from([64, 32]))
+    nrows = draw(st.integers(1, 10))
+    expo = draw(st.lists(st.floats(0.5, 10.5), min_size=nrows, max_size=nrows))
+    opts = {"ols_min_logn": draw(st.sampled_from([15, 16, 18]))}
+    if draw(st.booleans()):
+        opts["ols_big"] = draw(st.integers(0, 2))
+        opts["ols_small_max_halo"] = draw(st.sampled_from([0, 256, 512]))
+        opts["ols_fwd_weight"] = draw(st.sampled_from([0, 100, 1000]))
+    return N, n0, x_ld, nb, kind, param, np.array([2.0 ** e for e in expo]), prec, opts, draw(st.integers(0, 2 ** 31))
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(batch_cases())
+def test_random_batches_match_oracle(emu_library, case):
+    N, n0, x_ld, nb, kind, param, sj, prec, opts, seed = case
+    m = orc.Mother(kind, param)
+    with np.errstate(all="ignore"):
+        sj = sj[~np.isnan(m.psi_ft(sj * (-np.pi)))]
+    if sj.size == 0:
+        return
+    real, cplx, es = (np.float64, np.complex128, 8) if prec == 64 else (np.float32, np.complex64, 4)
+    X = np.zeros((nb, x_ld), dtype=real)
+    X[:, :n0] = np.random.default_rng(seed).standard_normal((nb, n0))
+    X[:, n0:] = 1e30                                          # the padding of the leading dimension must never be read
+    plan = _hip.Plan(N, prec, max_rows=nb * sj.size, lib=emu_library, options=opts)
+    xd = _hip.DeviceBuffer(X.nbytes, lib=emu_library)
+    xh = _hip.DeviceBuffer(nb * N * 2 * es, lib=emu_library)
+    Wd = _hip.DeviceBuffer(nb * sj.size * n0 * 2 * es, lib=emu_library)
+    xd.upload(plan, X)
+    plan.transform_batch(xd.ptr, nb, x_ld, n0, kind, param, 1.0, sj, xh.ptr, Wd.ptr, n0, n0)
+    got = Wd.download(plan, (nb, sj.size, n0), cplx)
+    classes = plan.row_classes()
+    for b in (xd, xh, Wd):
+        b.free()
+    plan.close()
+    tol = 1e-11 if prec == 64 else 5e-5
+    for b in range(nb):
+        ref = orc.cwt_rows(X[b, :n0].astype(np.float64), 1.0, sj, m, N=N)[:, :n0]
+        err = np.abs(got[b] - ref).max(axis=1)
+        scale = np.abs(ref).max(axis=1)
+        assert (err <= tol * scale).all(), (opts, b, [(c, e / s) for c, e, s in zip(classes[:sj.size], err, scale)])
