@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy target of the plan (cwt_plan_set_tolerance) against speed and measured error (GPU only).
 
-    python tools/tolerance_sweep.py [--config c2|c3_paul|c3_dog] [--tol 1e-16,1e-12,...] [--opt k=v]
+    python tests/perf/tolerance_sweep.py [--config c2|c3_paul|c3_dog] [--tol 1e-16,1e-12,...] [--opt k=v]
 
 For every target: the row classification, ms per step of the BASELINE workload (N = 2^20, 256 scales, wall clock around
 `steps` calls of cwt_transform, inputs resident) and -- every variant's W kept on the device -- the worst per-row error
@@ -16,7 +16,7 @@ from collections import Counter
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from pycwt_amd import _hip  # noqa: E402
