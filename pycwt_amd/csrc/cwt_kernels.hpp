@@ -30,6 +30,11 @@
 // Minimum resident waves per SIMD the compiler must allow for (second __launch_bounds__ argument, i.e. the VGPR
 // budget: 4 -> 128, 5 -> 96, 6 -> 80, 8 -> 64 registers) of the compile-time kernels, per precision.  Measured
 // defaults; override with -D for tuning runs.
+// Overlap-save block transforms with TB <= 2^this residues per tile use the padded exchange layout.  Measured with 3 and 4:
+// the bank conflicts of the TB = 8 / 16 stage-0 writes (16-36 % of those kernels' LDS cycles) go away, the step does not move.
+#ifndef CWT_OLS_PAD_LOGTB
+#define CWT_OLS_PAD_LOGTB 2
+#endif
 #ifndef CWT_LB_NARROW_F64
 #define CWT_LB_NARROW_F64 4
 #endif
@@ -1290,7 +1295,7 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
                                               cplx<T>* __restrict__ wout, int H, int nlim, T* lds, int logx, unsigned g) {
   // logx = log2(P_b / P), g < P_b / P: this workgroup's residues are r = g TB + t of the P_b / K of the block
   constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, NT = K >> 4, BD = 1 << (LOGP - 4);
-  using F = ct::Fft<T, LOGK, LOGTB, true, (LOGTB <= 2)>;
+  using F = ct::Fft<T, LOGK, LOGTB, true, (LOGTB <= CWT_OLS_PAD_LOGTB)>;
   F f;
   f.t = threadIdx.x & ((1 << LOGTB) - 1);
   f.j = threadIdx.x >> LOGTB;

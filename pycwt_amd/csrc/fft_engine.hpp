@@ -311,7 +311,7 @@ struct Fft {
   static constexpr bool WAVE_LOCAL = (!PLANES && NT <= 64) || WAVE;   // every FFT lives inside one wavefront
   static_assert(!WAVE || (PLANES && (TB * NT <= 64)), "WAVE: all FFTs of the instance inside one wavefront");
   static_assert(PLANES || LOGL >= 8, "ROWS layout needs L >= 256");
-  static_assert(!PADDED || (PLANES && LOGTB <= 3 && LOGL + LOGTB >= 8), "padded planes: TB <= 8, tile >= 256");
+  static_assert(!PADDED || (PLANES && LOGTB <= 4 && LOGL + LOGTB >= 8), "padded planes: TB <= 16, tile >= 256");
   static constexpr int LDS_ELEMS = (PLANES && !PADDED) ? (TB * L) : (TB * L + ((TB * L) >> 4));
 
   int t, j;   // FFT index in the workgroup, thread index in the FFT
