@@ -259,6 +259,10 @@ class Workload:
             "two_pass": (["pass_a", "pass_b"], [c for c in labels if c.startswith("two_pass")]),
             "ols_small": (["ols_small"], [c for c in labels if c.startswith("ols") and c.endswith("/half")]),
             "ols": (["ols"], [c for c in labels if c.startswith("ols") and not c.endswith("/half")]),
+            # rows clipped at Nyquist: overlap-save on the band-passed complex signal (aols_pre = that signal + its block spectra)
+            "aols": (["aols"], [c for c in labels if c.startswith("aols")]),
+            # band-limited rows in polynomial form (poly_coef = their interval coefficients, shared)
+            "poly": (["poly"], [c for c in labels if c.startswith("poly")]),
         }
         traffic_file, traffic_tab = None, {}
         tpath = os.path.join(ROOT, "profiles", f"traffic_{self.config}.json")
@@ -278,7 +282,7 @@ class Workload:
                                "launches_per_step": launches, "us_per_row": ms * 1e3 / len(rows),
                                "achieved_GBs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "traffic_ratio": (sum(t) / alg) if len(t) == len([k for k in kernels if k in kern]) and t else None}
-        shared = {k: kern[k]["ms_per_step"] for k in ("fwd_small", "fwd_pass_a", "fwd_pass_b", "ols_fwd") if k in kern}
+        shared = {k: kern[k]["ms_per_step"] for k in ("fwd_small", "fwd_pass_a", "fwd_pass_b", "ols_fwd", "aols_pre", "poly_coef") if k in kern}
         if not per_class:
             return {"bound": "hbm", "kernel": None, "kernels": kern, "row_split": split}
         dom = max(per_class, key=lambda k: per_class[k]["ms_per_step"])

@@ -335,6 +335,10 @@ int cwt_plan_read_stamps(cwt_plan* plan, uint64_t* out_host, int64_t cap_records
  * single pass with K = 2048 (fp64, 16384-point workgroups), [4] = band-limited single pass with K = 1024 and 5..16
  * aliased terms, [5] = overlap-save. */
 int cwt_plan_last_split(cwt_plan* plan, int counts[6]);
+/* The same with counts[6] = rows clipped at the Nyquist bins that ran as overlap-save rows on the band-passed complex
+ * signal (k_aols_*; before round 4 these were two-pass rows) and counts[7] = band-limited rows in polynomial form
+ * (k_poly_coef + k_poly_rows; counts[1], [3], [4] then only hold the band-limited rows that did not fit that form). */
+int cwt_plan_last_split8(cwt_plan* plan, int counts[8]);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ SYMBOLS = [
                                     C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("cwt_plan_last_split8", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("cwt_plan_balanced_shards", C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int64,
                                            C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("cwt_shard_codes", C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int),
@@ -398,6 +399,10 @@ class Plan:
                 out.append(30000 + (0 if parts[1] == "full" else int(np.log2(int(parts[1][1:])))) * 100 + 1)
             elif parts[0] == "narrow_k2048":
                 out.append(20000 + 1100 + int(parts[1][1:]))
+            elif parts[0] == "poly":
+                out.append(70000 + int(np.log2(int(parts[1][1:]))) * 100 + int(parts[2][1:]))
+            elif parts[0] == "aols":
+                out.append(60000 + int(np.log2(int(parts[1][1:]))) * 100 + 1)
             elif parts[0].startswith("ols"):
                 terms = int(parts[0][3:]) if len(parts[0]) > 3 else 1
                 kind = 5 if parts[-1] == "half" else 4
@@ -422,6 +427,10 @@ class Plan:
                 out.append(("ols/K" if terms == 1 else f"ols{terms}/K") + str(1 << logk))
             elif kind == 5:                                  # overlap-save row on half-size workgroup tiles
                 out.append(f"ols/K{1 << logk}/half")
+            elif kind == 7:                                  # band-limited row in polynomial form: K' intervals, degree d
+                out.append(f"poly/K{1 << logk}/d{terms}")
+            elif kind == 6:                                  # row clipped at Nyquist: overlap-save on the band-passed signal
+                out.append(f"aols/P{1 << logk}")
             else:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out
@@ -436,10 +445,10 @@ class Plan:
 
     @_locked
     def last_split(self):
-        c = (C.c_int * 6)()
-        self.lib.check(self.lib.cwt_plan_last_split(self.h, c))
+        c = (C.c_int * 8)()
+        self.lib.check(self.lib.cwt_plan_last_split8(self.h, c))
         return {"small": c[0], "narrow": c[1] + c[3] + c[4], "two_pass": c[2], "narrow_k2048": c[3], "narrow_many": c[4],
-                "ols": c[5]}
+                "ols": c[5], "aols": c[6], "poly": c[7]}
 
 
 class DeviceBuffer:

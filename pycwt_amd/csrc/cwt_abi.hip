@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -42,10 +43,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_MANY, KC_NARROW_BIG,
-                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_OLS_SMALL, KC_COUNT };
+                   KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_OLS_SMALL, KC_AOLS_PRE, KC_AOLS,
+                   KC_POLY_COEF, KC_POLY, KC_COUNT };
 const char* const kClassNames[KC_COUNT] = {"fwd_small", "fwd_pass_a",  "fwd_pass_b", "small",  "direct", "narrow",
                                            "narrow_many", "narrow_big", "pass_a",     "pass_b", "icwt",   "elementwise",
-                                           "ols_fwd", "ols", "ols_small"};
+                                           "ols_fwd", "ols", "ols_small", "aols_pre", "aols", "poly_coef", "poly"};
 
 int ilog2(int64_t v) {
   int l = 0;
@@ -192,6 +194,11 @@ struct cwt_plan {
   int ols = 1;             // overlap-save rows (time-compact wavelets) when the call hands over the signal itself
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
+  int poly = 1;            // band-limited rows in polynomial form (k_poly_coef + k_poly_rows) where they fit
+  int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
+  int poly_min_logn = 16;  // shortest transform that takes the form
+  int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
+  int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
@@ -222,6 +229,14 @@ struct cwt_plan {
   size_t z_bytes = 0;
   void* xs = nullptr;       // block spectra of the overlap-save rows
   size_t xs_bytes = 0;
+  void* pcoef = nullptr;    // interval coefficients of the polynomial rows
+  size_t pcoef_bytes = 0;
+  void* pband = nullptr;    // their filtered bands in transform-input order
+  size_t pband_bytes = 0;
+  void* xm = nullptr;       // band-passed complex signal x_M of the k_aols rows (N complex)
+  size_t xm_bytes = 0;
+  void* xsa = nullptr;      // its block spectra (nblocks x (P + 8) complex)
+  size_t xsa_bytes = 0;
   // buffers of cwt_execute_host
   void* hx = nullptr; size_t hx_bytes = 0;
   void* hxhat = nullptr; size_t hxhat_bytes = 0;
@@ -252,6 +267,18 @@ struct cwt_plan {
     long ols_xs_sig = 0;                 // ols_xs_sig elements apart; the rows carry their signal's offset in spec_off
     void* gt_dev = nullptr;              // filter tables of the overlap-save rows, written when the table is built
     size_t gt_bytes = 0;
+    // rows clipped at Nyquist on the band-passed complex signal (after the overlap-save rows), one halo class; the
+    // table entry at aux_first is the pseudo-row whose "filter" is the mask (profile 1 on the bins [k_s, N/2))
+    // band-limited rows in polynomial form (at the end of the table), grouped by K'
+    int n_poly = 0, poly_first = 0;
+    PolyClasses poly_cls{};
+    long poly_wgs = 0, poly_coef_elems = 0, poly_band_elems = 0;
+    int poly_max_logk = 8;
+    int n_aols = 0, aols_first = 0, aux_first = -1, aols_logp = 12;
+    AolsGeom aols_geom{};
+    long aols_wgs = 0, aols_gt_elems = 0;
+    void* agt_dev = nullptr;             // their (real) filter tables
+    size_t agt_bytes = 0;
     RowDesc* rows_dev = nullptr;
     RowDesc* rows_pinned = nullptr;
     hipEvent_t uploaded = nullptr;
@@ -260,8 +287,9 @@ struct cwt_plan {
   RowTable slots[2];
   RowTable* rt = &slots[0];
   uint64_t tick = 0;
-  int split[6] = {0, 0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
-                                       // band-limited K = 2048, band-limited K = 1024 with 5..16 terms, overlap-save
+  int split[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
+                                          // band-limited K = 2048, band-limited K = 1024 with 5..16 terms, overlap-save,
+                                          // overlap-save on the band-passed complex signal, polynomial form
   // Bluestein state for transform lengths n0 that are not powers of two (this plan's N is then M >= 2 n0 - 1)
   int64_t bs_n0 = 0;
   void* bs_khat[2] = {nullptr, nullptr};   // FFT_M of the chirp kernels: [0] e^{+pi i m^2/n0} (forward), [1] conjugate
@@ -461,6 +489,119 @@ int two_pass_logk(const cwt_plan* p);
 int check_geometry(const cwt_plan* p);
 int grow(void** buf, size_t* have, size_t need, hipStream_t s);
 
+
+// ---- rows clipped at Nyquist: overlap-save on the band-passed complex signal (k_aols_*) ------------------------
+// in-place radix-2 inverse DFT (e^{+2 pi i k n / n}, unnormalised) of a power-of-two length; host helper of aols_halo
+void host_ifft(std::vector<std::complex<double>>& v) {
+  const size_t n = v.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(v[i], v[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = 6.283185307179586476925 / double(len);
+    const std::complex<double> wl(std::cos(ang), std::sin(ang));
+    for (size_t i = 0; i < n; i += len) {
+      std::complex<double> w(1.0, 0.0);
+      for (size_t k = 0; k < len / 2; ++k) {
+        const std::complex<double> a = v[i + k], b = v[i + k + len / 2] * w;
+        v[i + k] = a + b;
+        v[i + k + len / 2] = a - b;
+        w *= wl;
+      }
+    }
+  }
+}
+
+double host_profile(int mother, double p, double f) {
+  if (mother == MOTHER_MORLET) return std::exp(-0.5 * (f - p) * (f - p));
+  if (mother == MOTHER_PAUL) return f > 0 ? std::exp(p * std::log(f) - f) : 0.0;
+  return std::pow(f, p) * std::exp(-0.5 * f * f);
+}
+
+// the window of k_aols_gtab (aols_window in cwt_kernels.hpp), on the host
+double host_aols_window(const AolsGeom& g, double f) {
+  if (f > 0.5) {
+    const double hw = 0.5 * (g.f_s + 0.5), c = 0.5 + hw;
+    return 0.5 * std::erfc(g.z * (f - c) / hw);
+  }
+  if (f < g.f1_lo) {
+    const double hw = 0.5 * (g.f1_lo - g.f_s), c = g.f_s + hw;
+    return hw > 0 ? 0.5 * std::erfc(g.z * (c - f) / hw) : 0.0;
+  }
+  return 1.0;
+}
+
+// Smallest halo H (multiple of 64, <= hmax) beyond which the kernel e = IFFT(E), E(f) = G(aN f) u(f), carries less than
+// eps of its L1 mass -- the bound on the relative error of an output sample, as for the overlap-save rows on the real
+// signal -- or 0 if there is none.  e is evaluated numerically on a 4 hmax-point grid (its wrap-around beyond 2 hmax
+// samples is far below eps for every row that passes).
+int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps, int hmax) {
+  const int n = 4 * hmax;
+  std::vector<std::complex<double>> e(size_t(n), std::complex<double>(0.0, 0.0));
+  const int k0 = int(std::ceil(g.f_s * n));
+  for (int q = 0; q < n; ++q) {
+    const int kappa = k0 + (((q - k0) % n) + n) % n;
+    const double f = double(kappa) / double(n);
+    e[size_t(q)] = host_profile(mother, param, aN * f) * host_aols_window(g, f);
+  }
+  host_ifft(e);
+  std::vector<double> ring(size_t(n / 2) + 1, 0.0);                 // |e| by distance from t = 0
+  double total = 0;
+  for (int t = 0; t < n; ++t) {
+    const double v = std::abs(e[size_t(t)]);
+    ring[size_t(std::min(t, n - t))] += v;
+    total += v;
+  }
+  if (!(total > 0)) return 0;
+  double tail = 0;
+  int best = 0;
+  for (int d = n / 2; d > 0; --d) {                                 // tail = mass at distance >= d
+    tail += ring[size_t(d)];
+    if (tail > eps * total) break;
+    if ((d - 1) % 64 == 0 && d - 1 >= 64 && d - 1 <= hmax) best = d - 1;   // halo H = d - 1 neglects distances > H
+  }
+  return best;
+}
+
+// z with erfc(z) / 2 = tail
+double erfc_arg(double tail) {
+  double lo = 0, hi = 10;
+  for (int it = 0; it < 100; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (0.5 * std::erfc(mid) > tail) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+
+
+// Degree of the polynomial form of a band-limited row (k_poly_*) on K' = 2^logk intervals: the smallest even D >= 2 with
+//   F(kappa) / F_max * |theta_kappa|^(D+1) / (D+1)!  <=  eps   on the band,  theta = pi kappa / K'
+// (F_max = the filter's largest value on the row's bins, log_best its log relative to the profile's peak) -- the truncated
+// Taylor terms are bounded like the bins beyond the support threshold.  The band is sampled at <= 257 points.
+int poly_degree_for(int mother, double param, double a, int kc, int k_lo, int nband, int logk, double log_best, double eps) {
+  const int npts = std::min(nband, 257);
+  const double tscale = 3.14159265358979323846 / double(1 << logk);
+  std::vector<double> term(static_cast<size_t>(npts), 0.0), th(static_cast<size_t>(npts), 0.0);
+  for (int i = 0; i < npts; ++i) {
+    const int k = k_lo + (npts > 1 ? int((long(nband - 1) * i) / (npts - 1)) : 0);
+    const double lg = profile_log_rel(mother, param, a * double(k)) - log_best;
+    term[size_t(i)] = std::isfinite(lg) ? std::exp(std::min(lg, 0.0)) : 0.0;
+    th[size_t(i)] = std::fabs(double(k - kc) + (k >= kc ? 1.0 : -1.0)) * tscale;   // + 1: the sampling skips neighbours
+  }
+  for (int d = 0; d <= POLY_MAX_DEGREE + 1; ++d) {
+    double worst = 0;
+    for (int i = 0; i < npts; ++i) {
+      term[size_t(i)] *= th[size_t(i)] / double(d + 1);
+      worst = std::max(worst, term[size_t(i)]);
+    }
+    if (worst <= eps && d >= 2 && (d & 1) == 0) return d;
+  }
+  return POLY_MAX_DEGREE + 2;
+}
+
 // Mother constant conj(c) with psi_ft(f) = c * profile(f)  (mothers.py:26-28, 118-122, 170-173)
 int mother_constant(int mother, double param, double* cre, double* cim) {
   const double pi = 3.14159265358979323846;
@@ -491,7 +632,7 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
 int build_row_table(cwt_plan* p, int mother, double param, const double* a, const double* amp_re,
                     const double* amp_im, int64_t spec_ld, int nrows, const int* tab_klo = nullptr,
                     const int* tab_nband = nullptr, int rows_per_signal = 0, int64_t tab_ld = -1,
-                    int64_t ols_ncols = 0) {
+                    int64_t ols_ncols = 0, int64_t out_ncols = 0) {
   const int64_t N = p->N;
   double f_lo = 0, f_hi = 0;
   if (mother < MOTHER_MORLET || mother > MOTHER_TABLE) return fail(CWT_EINVAL, "unknown mother id");
@@ -534,9 +675,17 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const double ols_ch = ols_ok ? time_halo_factor(mother, param, tol.halo) : 0.0;
   // "not clipped at Nyquist": the profile at the Nyquist bins is below this fraction of its peak (the jump there is what
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
+  // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*): needs the spectrum only;
+  // Morlet and Paul (a real mother constant and nothing to keep on the masked-out bins), one shared spectrum
+  const bool aols_ok = p->ols && p->aols && out_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) &&
+                       p->logN >= p->ols_min_logn && (mother == MOTHER_MORLET || mother == MOTHER_PAUL) &&
+                       rows_per_signal == 0 && spec_ld == 0 && !use_small;
   double fc_lo = 0, fc_hi = 0;
-  if (ols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
-  std::vector<RowDesc> narrow_rows, wide_rows, small_rows;
+  if (ols_ok || aols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
+  std::vector<RowDesc> narrow_rows, wide_rows, small_rows, poly_rows;
+  std::vector<char> wide_clipped;
+  const bool poly_ok = p->poly && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && mother != MOTHER_TABLE &&
+                       p->logN >= std::max(POLY_LOGP, p->poly_min_logn) && !use_small;
   struct OlsRow { RowDesc rd; int grp, lb, h64; };
   std::vector<OlsRow> ols_rows;
   for (int j = 0; j < nrows; ++j) {
@@ -548,7 +697,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     // batched signals: row j belongs to signal j / rows_per_signal, whose spectrum starts at spec_ld * that
     rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
-    double row_lo = f_lo, row_hi = f_hi;
+    rd.aux_off = 0;
+    double row_lo = f_lo, row_hi = f_hi, row_best = 0.0;     // row_best: log of the filter's largest value on the row's bins / its peak
     if (mother != MOTHER_TABLE) {
       // The support threshold is meant relative to the largest value the filter takes ON THE ROW'S BINS.  Where the bins
       // are coarser than the profile (a >~ 1: the largest scales) that is far below the profile's own peak: the
@@ -564,12 +714,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       if (std::isfinite(best) && best < std::log(0.25)) {
         const double eps_row = std::max(tol.support * std::exp(best), 1e-300);
         profile_support(mother, param, eps_row, &row_lo, &row_hi);
+        row_best = best;
       }
     }
     double klo = std::ceil(row_lo / rd.a), khi = std::floor(row_hi / rd.a);
     if (mother == MOTHER_PAUL) klo = std::max(klo, 1.0);
-    const bool unclipped = ols_ok && std::ceil(fc_lo / rd.a) > -double(N / 2) &&      // F_j vanishes at the Nyquist bins
-                           std::floor(fc_hi / rd.a) < double(N / 2 - 1);
+    const bool vanishes = std::ceil(fc_lo / rd.a) > -double(N / 2) &&                 // F_j vanishes at the Nyquist bins
+                          std::floor(fc_hi / rd.a) < double(N / 2 - 1);
+    const bool unclipped = ols_ok && vanishes;
     klo = std::max(klo, -double(N / 2));
     khi = std::min(khi, double(N / 2 - 1));
     if (mother == MOTHER_TABLE) { klo = tab_klo[j]; khi = klo + tab_nband[j] - 1; }
@@ -653,7 +805,24 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           else halo = 0;
         }
       }
-      if (p->narrow && need <= narrow_cap) {
+      // polynomial form (k_poly_coef / k_poly_rows): K' >= the support intervals of R = N / K' >= 64 samples (128 in
+      // complex64: a lane stores two outputs), degree D from the filter-weighted truncation rule
+      int poly_logk = 0, poly_deg = 0;
+      if (poly_ok && rd.nband > 0) {
+        const int lk_max = std::min(14, p->logN - POLY_MIN_LOGR);
+        const int kc = rd.k_lo + (rd.nband >> 1);
+        for (int lk = std::max(8, ilog2(rd.nband)); lk <= lk_max; ++lk) {
+          const int deg = poly_degree_for(mother, param, rd.a, kc, rd.k_lo, rd.nband, lk, row_best, tol.support);
+          if (deg > POLY_MAX_DEGREE) continue;
+          poly_logk = lk; poly_deg = deg;
+          if (deg <= p->poly_degree) break;
+        }
+      }
+      if (poly_logk) {
+        rd.logK = poly_logk;
+        rd.nterms = poly_deg;
+        poly_rows.push_back(rd);
+      } else if (p->narrow && need <= narrow_cap) {
         rd.logK = need;
         narrow_rows.push_back(rd);
       } else if (halo) {
@@ -672,7 +841,70 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         const int cls = span <= 16 ? 4 : span <= 64 ? 6 : span <= 256 ? 8 : 0;
         rd.logK = (band_pass_a && cls && cls < two_pass_logr) ? cls : 0;   // only if shorter than the column
         wide_rows.push_back(rd);
+        wide_clipped.push_back(aols_ok && !vanishes && rd.nband > 0 && amp_im[j] == 0.0);
       }
+    }
+  }
+  // Rows clipped at Nyquist (so far two-pass rows) that can run as overlap-save rows on the band-passed complex signal:
+  // one mask and one window for all of them (from the smallest scale), the halo of each from its kernel, one halo class.
+  std::vector<RowDesc> aols_rows;
+  AolsGeom ag{};
+  int aols_logp = 12, aols_ks = 1;
+  if (aols_ok) {
+    double a_min = 0;
+    for (size_t i = 0; i < wide_rows.size(); ++i)
+      if (wide_clipped[i] && (a_min == 0 || wide_rows[i].a < a_min)) a_min = wide_rows[i].a;
+    bool geom_ok = a_min > 0;
+    if (geom_ok) {
+      ag.z = erfc_arg(std::max(tol.halo * 0.1, 1e-19));
+      if (mother == MOTHER_MORLET) {
+        // the filter of the smallest scale is above the support threshold from f1_lo on (negative: Morlet's Gaussian is
+        // not gated at f = 0, mothers.py:26-28); below it a taper of 1/32 cycle per sample, then the mask ends
+        double s_lo, s_hi;
+        profile_support(mother, param, tol.support, &s_lo, &s_hi);
+        ag.f1_lo = std::min(s_lo / (a_min * double(N)), 0.0);
+        ag.f_s = ag.f1_lo - 1.0 / 32.0;
+        if (0.5 + ag.f_s < 0.12) ag.f_s = ag.f1_lo - 1.0 / 128.0;
+        geom_ok = 0.5 + ag.f_s >= 0.10;                   // room for the taper above Nyquist
+        aols_ks = int(std::ceil(ag.f_s * double(N)));
+      } else {                                             // Paul: Heaviside -- the mask starts at bin 1
+        ag.f1_lo = ag.f_s = 1.0 / double(N);
+        aols_ks = 1;
+      }
+    }
+    std::vector<int> halos(wide_rows.size(), 0);
+    int hmax_seen = 0, cnt = 0;
+    if (geom_ok) {
+      const double eps = std::max(tol.halo, p->prec == 64 ? 2e-14 : 5e-7);
+      for (size_t i = 0; i < wide_rows.size(); ++i) {
+        if (!wide_clipped[i]) continue;
+        halos[i] = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512);
+        if (halos[i]) { ++cnt; hmax_seen = std::max(hmax_seen, halos[i]); }
+      }
+    }
+    if (geom_ok && cnt >= std::max(1, p->aols_min_rows)) {
+      aols_logp = 12;                                      // 4096-point tiles: four block transforms in flight per CU
+      const int P = 1 << aols_logp, L = P - 2 * hmax_seen;
+      ag.halo = hmax_seen;
+      ag.nrows = cnt;
+      ag.nblocks = int((out_ncols + L - 1) / L);
+      ag.ksp = int(std::ceil(ag.f_s * double(P)));
+      std::vector<RowDesc> keep;
+      long toff = 0;
+      for (size_t i = 0; i < wide_rows.size(); ++i) {
+        if (!halos[i]) { keep.push_back(wide_rows[i]); continue; }
+        RowDesc o = wide_rows[i];
+        o.a = wide_rows[i].a * double(N >> aols_logp);     // profile argument per block bin
+        o.amp_re = amp_re[o.out_row] / double(P);          // 1/P of the block's inverse transform (x_M carries its own 1/N)
+        o.amp_im = 0.0;
+        o.k_lo = ag.ksp; o.nband = P;
+        o.logK = aols_logp; o.nterms = 1;
+        o.spec_off = 0;
+        o.tab_off = toff;
+        toff += P;
+        aols_rows.push_back(o);
+      }
+      wide_rows.swap(keep);
     }
   }
   // launch classes, in table order: 0 = k_narrow_ct_all (K <= 1024, <= 4 terms), 1 = k_narrow_ct_many (K = 1024,
@@ -827,6 +1059,61 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     p->rt->ols_xs_elems = xs * ols_nbatch;
   }
   p->rt->ols_nbatch = ols_nbatch;
+  p->rt->aols_first = int(p->rt->table.size());
+  p->rt->n_aols = int(aols_rows.size());
+  p->rt->aux_first = -1;
+  p->rt->aols_gt_elems = 0;
+  if (!aols_rows.empty()) {
+    p->rt->table.insert(p->rt->table.end(), aols_rows.begin(), aols_rows.end());
+    p->rt->aols_logp = aols_logp;
+    p->rt->aols_geom = ag;
+    p->rt->aols_wgs = long((ag.nblocks + 7) / 8) * 8 * ag.nrows;
+    p->rt->aols_gt_elems = long(aols_rows.size()) << aols_logp;
+    RowDesc m{};                                          // the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)
+    m.a = 0.0; m.amp_re = 1.0 / double(N); m.amp_im = 0.0;
+    m.k_lo = aols_ks; m.nband = int(N / 2) - aols_ks;
+    m.out_row = 0; m.logK = 0; m.nterms = 1; m.spec_off = 0; m.tab_off = 0;
+    p->rt->aux_first = int(p->rt->table.size());
+    p->rt->table.push_back(m);
+  }
+  // polynomial rows: by K', then by degree; coefficient offsets; the workgroups of k_poly_coef per class
+  p->rt->poly_first = int(p->rt->table.size());
+  p->rt->n_poly = int(poly_rows.size());
+  p->rt->poly_cls.n = 0;
+  p->rt->poly_wgs = p->rt->poly_coef_elems = 0;
+  if (!poly_rows.empty()) {
+    std::stable_sort(poly_rows.begin(), poly_rows.end(), [](const RowDesc& x, const RowDesc& y) {
+      return x.logK != y.logK ? x.logK < y.logK : x.nterms < y.nterms;
+    });
+    long off = 0, wg = 0, boff = 0;
+    p->rt->poly_max_logk = 8;
+    for (size_t i = 0; i < poly_rows.size(); ++i) {
+      RowDesc& r = poly_rows[i];
+      r.tab_off = off;                                      // planes: (D + 1) K' complex
+      off += (long(r.nterms) + 1) << r.logK;
+      r.aux_off = boff;                                     // band: K' complex
+      boff += 1L << r.logK;
+      p->rt->poly_max_logk = std::max(p->rt->poly_max_logk, r.logK);
+      PolyClasses& pc = p->rt->poly_cls;
+      if (pc.n == 0 || pc.c[pc.n - 1].logK != r.logK) {
+        if (pc.n == POLY_MAX_CLASSES) return fail(CWT_EINVAL, "too many polynomial-row classes");
+        pc.c[pc.n++] = PolyClass{r.logK, int(i), 0, 0, 0};
+      }
+      PolyClass& c = pc.c[pc.n - 1];
+      c.nrows++;
+      c.ndeg = std::max(c.ndeg, r.nterms + 1);
+    }
+    for (int i = 0; i < p->rt->poly_cls.n; ++i) {
+      PolyClass& c = p->rt->poly_cls.c[i];
+      const long tb = 1L << (POLY_LOGP - c.logK);
+      c.wg_first = int(wg);
+      wg += (long(c.nrows) * c.ndeg + tb - 1) / tb;
+    }
+    p->rt->poly_wgs = wg;
+    p->rt->poly_coef_elems = off;
+    p->rt->poly_band_elems = boff;
+    p->rt->table.insert(p->rt->table.end(), poly_rows.begin(), poly_rows.end());
+  }
   return CWT_OK;
 }
 
@@ -838,7 +1125,8 @@ void set_split(cwt_plan* p) {
     else if (g.nterms > 4) n_many += g.count;
   }
   p->split[0] = p->rt->n_small; p->split[1] = p->rt->n_narrow - n_big - n_many; p->split[2] = p->rt->n_wide;
-  p->split[3] = n_big; p->split[4] = n_many; p->split[5] = p->rt->n_ols;
+  p->split[3] = n_big; p->split[4] = n_many; p->split[5] = p->rt->n_ols; p->split[6] = p->rt->n_aols;
+  p->split[7] = p->rt->n_poly;
 }
 
 int chunk_rows_of(const cwt_plan* p) {
@@ -1311,6 +1599,89 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
   return rc;
 }
 
+// Rows clipped at Nyquist (k_aols_*): band-passed complex signal x_M = IFFT_N(xhat mask) through the two-pass kernels
+// (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
+template <typename T, int LOGP>
+int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  const cwt_plan::RowTable* rt = p->rt;
+  const AolsGeom& g = rt->aols_geom;
+  constexpr int P = 1 << LOGP;
+  int rc = grow(&p->xm, &p->xm_bytes, size_t(p->N) * sizeof(cplx<T>), st);
+  if (!rc) rc = grow(&p->xsa, &p->xsa_bytes, size_t(g.nblocks) * size_t(P + 8) * sizeof(cplx<T>), st);
+  if (!rc) rc = ensure_z(p, 1);
+  if (rc) return rc;
+  const int logK = two_pass_logk(p), logR = p->logN - logK;
+  Mother one;
+  one.kind = MOTHER_DOG; one.m = 0; one.p = 0.0; one.table = nullptr;       // profile(0 * k) = 1
+  cplx<T>* Z = static_cast<cplx<T>*>(p->Z);
+  cplx<T>* xm = static_cast<cplx<T>*>(p->xm);
+  bool ok = true;
+  rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    ok = try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rt->rows_dev + rt->aux_first, 1, one, 0L, 0L, Z, st);
+  }, st);
+  if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
+  if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    ok = try_pass_b_ct<T, false>(p, logK, nullptr, 1, xm, p->N, p->N, Z, st);
+  }, st);
+  if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
+  if (rc) return rc;
+  static const bool once = (allow_big_lds(&k_aols_fwd<T, LOGP>), allow_big_lds(&k_aols_rows<T, LOGP>), true);
+  (void)once;
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks)), dim3(1 << (LOGP - 4)), lds, st, xm, p->logN, g.halo,
+                       static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
+  }, st);
+  if (rc) return rc;
+  return timed_launch(p, KC_AOLS, [&] {
+    hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs)), dim3(1 << (LOGP - 4)), lds, st,
+                       static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first,
+                       static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g, W, long(ldw), long(ncols));
+  }, st);
+}
+template <typename T>
+int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  switch (p->rt->aols_logp) {
+    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st);
+    default: return fail(CWT_EINVAL, "k_aols tile size");
+  }
+}
+
+// Band-limited rows in polynomial form: interval coefficients (k_poly_coef), then the streaming kernel (k_poly_rows).
+template <typename T>
+int launch_poly(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  const cwt_plan::RowTable* rt = p->rt;
+  int rc = grow(&p->pcoef, &p->pcoef_bytes, size_t(rt->poly_coef_elems) * sizeof(cplx<T>), st);
+  if (!rc) rc = grow(&p->pband, &p->pband_bytes, size_t(rt->poly_band_elems) * sizeof(cplx<T>), st);
+  if (rc) return rc;
+  static const bool once = (allow_big_lds(&k_poly_coef<T>), true);
+  (void)once;
+  const RowDesc* rows = rt->rows_dev + rt->poly_first;
+  cplx<T>* coef = static_cast<cplx<T>*>(p->pcoef);
+  cplx<T>* band = static_cast<cplx<T>*>(p->pband);
+  rc = timed_launch(p, KC_POLY_COEF, [&] {
+    for (int r0 = 0; r0 < rt->n_poly; r0 += kMaxGridY)
+      hipLaunchKernelGGL((k_poly_band<T>), dim3(1u << (rt->poly_max_logk - 8), std::min(kMaxGridY, rt->n_poly - r0)), dim3(256), 0, st,
+                         xhat, rows + r0, mo, twn_of<T>(p), p->logN, band);
+  }, st);
+  if (rc) return rc;
+  rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T>), dim3(unsigned(rt->poly_wgs)), dim3(1 << (POLY_LOGP - 4)),
+                       ((size_t(1) << POLY_LOGP) + (size_t(1) << (POLY_LOGP - 4))) * sizeof(T), st,
+                       static_cast<const cplx<T>*>(band), rows, static_cast<const cplx<T>*>(p->tw_all), rt->poly_cls, coef);
+  }, st);
+  if (rc) return rc;
+  const int64_t per_wg = 256 * (sizeof(T) == 8 ? 1 : 2) * POLY_PASSES;
+  // LDS: the coefficient sets of the intervals one workgroup touches (shortest interval 2^POLY_MIN_LOGR samples)
+  const size_t lds2 = size_t((per_wg >> POLY_MIN_LOGR) + 2) * (POLY_MAX_DEGREE + 1) * sizeof(cplx<T>);
+  return timed_launch(p, KC_POLY, [&] {
+    for (int r0 = 0; r0 < rt->n_poly; r0 += kMaxGridY)
+      hipLaunchKernelGGL((k_poly_rows<T>), dim3(unsigned((ncols + per_wg - 1) / per_wg), std::min(kMaxGridY, rt->n_poly - r0)),
+                         dim3(256), lds2, st, rows + r0, static_cast<const cplx<T>*>(coef), twn_of<T>(p), p->logN, W,
+                         long(ldw), long(ncols));
+  }, st);
+}
+
 // Restores the plan's stream when a scope that redirected launches to a side stream is left on any path.
 struct StreamGuard {
   cwt_plan* p;
@@ -1372,8 +1743,8 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   if (p->rt->n_ols && !x_dev) return fail(CWT_EINVAL, "overlap-save rows need the signal");
   // (short transforms run their kernels back to back: at N = 2^16 / 2^17 the events and waits of the side streams cost
   // more than the overlap returns -- measured 0.149 against 0.129 ms and 0.226 against 0.204 ms per 256-row transform)
-  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols) &&
-                           p->rt->n_narrow && logN >= 18;
+  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols || p->rt->n_aols) &&
+                           (p->rt->n_narrow || p->rt->n_poly) && logN >= 18;
   // block spectra of the overlap-save rows: beside the two-pass chain on side stream 1 (they only need the signal)
   const bool ols_early = p->rt->n_ols && p->ols_launched;       // already queued on side stream 1 by cwt_transform
   const bool ols_side = p->rt->n_ols && !ols_early && p->ols_side && !p->profile && !p->overlap && p->rt->n_wide;
@@ -1429,6 +1800,10 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
       if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
   }
+  if (p->rt->n_aols) {                 // after the two-pass chain: both use the intermediate buffer
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, p->stream);
+    if (rc) return rc;
+  }
   if (ols_early) {
     HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
   } else if (p->rt->n_ols) {
@@ -1448,6 +1823,12 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
   // tails) when "overlap_narrow" is set, else on the plan's own stream
   bool narrow_on_side = false;
+  if (p->rt->n_poly) {                 // on the side stream of the band-limited rows (joined below), else on the plan's
+    narrow_on_side = side_narrow;
+    rc = launch_poly<T>(p, xhat, mo, W, ldw, ncols, narrow_on_side ? p->side[0] : p->stream);
+    if (rc) return rc;
+    if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
+  }
   if (p->rt->n_narrow) {
     if (narrow_ct_all_applies<T>(p)) {
       StreamGuard guard(p);                                 // p->stream is redirected below; restored on every path
@@ -1645,9 +2026,10 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
-    if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+    // (+ 4: pseudo-rows such as the mask of the k_aols rows)
+    if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows + 4) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "row table allocation failed");
-    if (!rc && hipHostMalloc(reinterpret_cast<void**>(&t.rows_pinned), size_t(max_rows) * sizeof(RowDesc)) != hipSuccess)
+    if (!rc && hipHostMalloc(reinterpret_cast<void**>(&t.rows_pinned), size_t(max_rows + 4) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "pinned row table allocation failed");
     if (!rc && hipEventCreate(&t.uploaded) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   }
@@ -1679,11 +2061,12 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->hx, p->hxhat, p->hW, p->stamps,
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->hx, p->hxhat, p->hW, p->stamps,
                   p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
     if (t.gt_dev) (void)hipFree(t.gt_dev);
+    if (t.agt_dev) (void)hipFree(t.agt_dev);
     if (t.rows_dev) (void)hipFree(t.rows_dev);
     if (t.rows_pinned) (void)hipHostFree(t.rows_pinned);
     if (t.uploaded) (void)hipEventDestroy(t.uploaded);
@@ -1760,6 +2143,11 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
   else if (k == "sched") p->sched = int(value);
   else if (k == "ols") p->ols = value != 0;
+  else if (k == "aols") p->aols = value != 0;
+  else if (k == "poly") p->poly = value != 0;
+  else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
+  else if (k == "poly_min_logn") { if (value < 14 || value > 24) return fail(CWT_EINVAL, "poly_min_logn in [14, 24]"); p->poly_min_logn = int(value); }
+  else if (k == "aols_min_rows") { if (value < 1 || value > 65536) return fail(CWT_EINVAL, "aols_min_rows >= 1"); p->aols_min_rows = int(value); }
   else if (k == "ols_side") p->ols_side = value != 0;
   else if (k == "ols_big") { if (value < 0 || value > 2) return fail(CWT_EINVAL, "ols_big: 0, 1 (blocks of two tiles) or 2 (also of four)"); p->ols_big = int(value); }
   else if (k == "ols_big4_max_halo") { if (value < 2048 || value > 8192 || (value & 63)) return fail(CWT_EINVAL, "ols_big4_max_halo: multiple of 64 in [2048, 8192]"); p->ols_big4_max_halo = int(value); }
@@ -1903,12 +2291,28 @@ int fill_ols_tables(cwt_plan* p, const Mother& mo) {
   return CWT_OK;
 }
 
+// Filter tables of the rows on the band-passed complex signal (k_aols_gtab), on the plan's stream.
+template <typename T>
+int fill_aols_tables(cwt_plan* p, const Mother& mo) {
+  cwt_plan::RowTable* t = p->rt;
+  int rc = grow(&t->agt_dev, &t->agt_bytes, size_t(t->aols_gt_elems) * sizeof(T), p->stream);
+  if (rc) return rc;
+  const int P = 1 << t->aols_logp;
+  const dim3 grid(P / 256, t->n_aols), block(256);
+  const RowDesc* rows = t->rows_dev + t->aols_first;
+  T* gt = static_cast<T*>(t->agt_dev);
+  if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
+  else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
+  HIPCHECK(hipGetLastError());
+  return CWT_OK;
+}
+
 int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, double dt, const double* scales,
                        int nrows, int64_t ldw, int64_t ncols) {
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
-  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), have_signal ? double(ncols) : 0.0},
+  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), have_signal ? 1.0 : 0.0, double(ncols)},
                                            {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -1924,10 +2328,12 @@ int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, 
       ai[j] = norm * cim;
     }
     rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), 0, nrows, nullptr, nullptr, 0, -1,
-                         have_signal ? ncols : 0);
+                         have_signal ? ncols : 0, ncols);
     if (!rc) rc = upload_row_table(p, key);
     if (!rc && p->rt->n_ols)
       rc = p->prec == 64 ? fill_ols_tables<double>(p, mother_of(mother, param)) : fill_ols_tables<float>(p, mother_of(mother, param));
+    if (!rc && p->rt->n_aols)
+      rc = p->prec == 64 ? fill_aols_tables<double>(p, mother_of(mother, param)) : fill_aols_tables<float>(p, mother_of(mother, param));
     if (rc) { p->rt->key.clear(); return rc; }
   }
   set_split(p);
@@ -1978,7 +2384,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
   if (!xhat_dev) {   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
-    if (p->rt->n_ols == int(p->rt->table.size())) {
+    if (p->rt->n_ols == nrows) {                          // every row is an overlap-save row on the real signal
       const Mother mo = mother_of(mother, param);
       return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                            : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
@@ -2507,14 +2913,17 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
 int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
   if (!p || !n) return fail(CWT_EINVAL, "NULL argument");
   const int total = int(p->rt->table.size());
-  *n = total;
+  *n = total - (p->rt->aux_first >= 0 ? 1 : 0);
   if (!codes) return CWT_OK;
   for (int i = 0; i < total; ++i) {
     const RowDesc& rd = p->rt->table[i];
     // 0 single-workgroup, 1 band-limited, 2 band-limited K = 2048, 3 two-pass, 4 overlap-save, 5 overlap-save on half-size tiles
     const int small_end = p->rt->ols_first + (p->rt->ols_grp[0].logp != p->rt->ols_grp[1].logp ? p->rt->ols_grp[0].nrows : 0);
+    if (i == p->rt->aux_first) continue;                 // the mask pseudo-row of the k_aols rows
+    // ... 6 overlap-save on the band-passed complex signal (rows clipped at Nyquist)
+    // 7 band-limited row in polynomial form (logK = log2 of its interval count, nterms = its degree)
     const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : i < p->rt->ols_first ? 3 :
-                     i < small_end ? 5 : 4;
+                     i >= p->rt->poly_first ? 7 : i >= p->rt->aols_first ? 6 : i < small_end ? 5 : 4;
     if (rd.out_row >= 0 && rd.out_row < cap) codes[rd.out_row] = kind * 10000 + rd.logK * 100 + rd.nterms;
   }
   return CWT_OK;
@@ -2535,15 +2944,16 @@ namespace {
 // Cost model of one rank's step, microseconds at N = 2^20: per kernel class a fixed part (launch ramp and tail; for the
 // overlap-save classes the block spectra of that tile size) + a per-row part.  Fitted to the per-class launch durations of
 // bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt.
-struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term; };
-constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.4, 8.0, 2.85, 0.9};
-constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55};
+struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term,
+                   aols_fixed, aols_row, poly_fixed, poly_row; };
+constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.4, 8.0, 2.85, 0.9, 40.0, 4.0, 20.0, 2.6};
+constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55, 35.0, 2.3, 18.0, 1.4};
 
 // Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
 // length / 2^20: per-row parts scale with it, per-launch parts do not; chunk = rows per two-pass launch pair.
 double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double nscale, int chunk) {
   double total = 0;
-  bool seen_tp = false, seen_big = false, seen_ols = false, seen_olsh = false, seen_nar = false;
+  bool seen_tp = false, seen_big = false, seen_ols = false, seen_olsh = false, seen_nar = false, seen_aols = false, seen_poly = false;
   int n_tp = 0;
   for (int i = lo; i < hi; ++i) {
     const int kind = codes[i] / 10000, logk = (codes[i] / 100) % 100, terms = codes[i] % 100;
@@ -2551,6 +2961,8 @@ double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double n
     else if (kind == 2) { if (!seen_big) { seen_big = true; total += c.k2048_fixed; } total += c.k2048_row * nscale; }
     else if (kind == 4) { if (!seen_ols) { seen_ols = true; total += c.ols_fixed; } total += c.ols_row * nscale; }
     else if (kind == 5) { if (!seen_olsh) { seen_olsh = true; total += c.olsh_fixed; } total += c.olsh_row * nscale; }
+    else if (kind == 7) { if (!seen_poly) { seen_poly = true; total += c.poly_fixed; } total += c.poly_row * nscale * (1.0 + 0.015 * std::max(0, terms - 8)); }
+    else if (kind == 6) { if (!seen_aols) { seen_aols = true; total += c.aols_fixed * std::max(nscale, 0.5); } total += c.aols_row * nscale; }
     else {
       if (!seen_nar) { seen_nar = true; total += c.nar_fixed; }
       const double per = c.nar_row * nscale;
@@ -2563,7 +2975,7 @@ double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double n
     }
   }
   if (n_tp > chunk) total += c.tp_fixed * ((n_tp - 1) / chunk);
-  if (seen_tp || seen_big || seen_nar) total += c.fwd * std::max(nscale, 0.5);   // some row needs the spectrum
+  if (seen_tp || seen_big || seen_nar || seen_aols || seen_poly) total += c.fwd * std::max(nscale, 0.5);   // some row needs the spectrum
   return total;
 }
 }  // namespace
@@ -2650,6 +3062,12 @@ int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, i
 int cwt_plan_last_split(cwt_plan* p, int counts[6]) {
   if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
   for (int i = 0; i < 6; ++i) counts[i] = p->split[i];
+  return CWT_OK;
+}
+
+int cwt_plan_last_split8(cwt_plan* p, int counts[8]) {
+  if (!p || !counts) return fail(CWT_EINVAL, "NULL argument");
+  for (int i = 0; i < 8; ++i) counts[i] = p->split[i];
   return CWT_OK;
 }
 

@@ -84,7 +84,9 @@ struct RowDesc {
   int logK;        // k_narrow: log2 of this row's FFT length
   int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
   long spec_off;   // element offset of this row's spectrum (0: all rows share one spectrum)
-  long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N)
+  long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N); rows with tables or coefficient
+                   // planes of their own (overlap-save, polynomial): element offset of those
+  long aux_off;    // polynomial rows: element offset of the row's filtered band (k_poly_band)
 };
 
 struct Mother {
@@ -243,7 +245,7 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
     RowDesc rd;
-    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; }
+    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; rd.aux_off = 0; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = g.j + (e << logNT);
@@ -1403,6 +1405,331 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
     default: ols_full_body<T, LOGP>(xb, rd, gt, tw_all, wout, H, nlim, lds); break;
   }
 #undef CWT_OLS_CASE
+}
+
+// =============================================================================================
+// Overlap-save rows on the BAND-PASSED COMPLEX signal (k_aols_*): rows whose filter is CLIPPED at the Nyquist bins.
+//
+// F_j[k] = amp G(a k) on the signed bins k in [-N/2, N/2) (wavelet.py:94, 102-104).  Where G has not died out at the
+// Nyquist bins the cyclic filter jumps there, h_j = IFFT_N(F_j) has a 1/t tail and no overlap-save on the real signal is
+// possible (these rows were the two-pass rows: 48 B per sample*scale).  But with a mask over the bins [k_s, N/2),
+//     xhat F_j  =  (xhat mask) E_j,     E_j(f) = amp G(a N f) u(f),  f = k/N in [f_s, f_s + 1),
+// where G is continued PAST Nyquist (f > 1/2: no wrap) and u is a smooth window: 1 on the part of the mask that carries
+// the filter, erfc tapers over the rest of the circle.  E_j is cyclically smooth, so its kernel e_j is short (the wavelet
+// itself convolved with the taper's kernel), and W_j = x_M (*) e_j is an overlap-save convolution of the complex
+// band-passed signal x_M = IFFT_N(xhat mask), which is computed ONCE per transform (one two-pass row) and shared by all
+// such rows.  Valid because xhat mask vanishes wherever E_j differs from F_j: Morlet's negative-frequency part (below the
+// support threshold from bin k_s down), Paul's Heaviside (k_s = 1).
+struct AolsGeom {
+  int nrows;       // rows of the class
+  int nblocks;     // output blocks of L = P - 2 halo columns
+  int halo;        // H (multiple of 64)
+  int ksp;         // first unwrapped bin of the block grid: a block bin q stands for kappa = ksp + ((q - ksp) mod P)
+  double f_s;      // low edge of the mask in cycles per sample (<= 1/N)
+  double f1_lo;    // the window is 1 on [f1_lo, 1/2]
+  double z;        // erfc argument at the ends of a taper: u = erfc(z)/2 there
+};
+
+// window u(f), f in [f_s, f_s + 1)
+__device__ __forceinline__ double aols_window(const AolsGeom& g, double f) {
+  if (f > 0.5) {
+    const double hw = 0.5 * (g.f_s + 0.5), c = 0.5 + hw;
+    return 0.5 * erfc(g.z * (f - c) / hw);
+  }
+  if (f < g.f1_lo) {
+    const double hw = 0.5 * (g.f1_lo - g.f_s), c = g.f_s + hw;
+    return hw > 0 ? 0.5 * erfc(g.z * (c - f) / hw) : 0.0;
+  }
+  return 1.0;
+}
+
+// Filter tables of those rows: gt[tab_off + q] = amp_re * G(a_b kappa(q)) u(kappa(q) / P), q < P, real (the mother's
+// constant is real for Morlet and Paul).  Evaluated in double for either precision; once per scale grid.
+template <typename T, int MK>
+__global__ void k_aols_gtab(const RowDesc* __restrict__ rows, Mother mo, int logP, AolsGeom g, T* __restrict__ gt) {
+  const RowDesc rd = rows[blockIdx.y];
+  const int P = 1 << logP, q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P) return;
+  const int kappa = g.ksp + ((q - g.ksp) & (P - 1));
+  const double v = profile_k<double, MK>(mo, rd.a * double(kappa)) * aols_window(g, double(kappa) / double(P));
+  gt[rd.tab_off + q] = T(v * rd.amp_re);
+}
+
+// Spectra of the input blocks of x_M (complex, N-periodic): block b covers x_M[b L - H .. b L - H + P).  One workgroup
+// per block, forward transform as conj(inverse(conj)); all P bins are kept (x_M is not real).
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
+k_aols_fwd(const cplx<T>* __restrict__ xm, int logN, int halo, const cplx<T>* __restrict__ tw_all,
+           cplx<T>* __restrict__ xs) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int P = 1 << LOGP, NT = P >> 4;
+  using F = ct::Fft<T, LOGP, 0, false>;
+  const long nmask = (1L << logN) - 1;
+  const long first = long(blockIdx.x) * (P - 2 * halo) - halo;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const cplx<T> v = xm[(first + f.j + e * NT) & nmask];
+    re[e] = v.x; im[e] = -v.y;
+  }
+  f.run(re, im, lds, tw_all + (P - 2));
+  cplx<T>* out = xs + long(blockIdx.x) * (P + 8);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[f.j + e * NT] = mk<T>(re[e], -im[e]);
+}
+
+// The rows: workgroup = (block, row).  The 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of it back to
+// back, so that a block spectrum is fetched into one L2 once.  y = IFFT_P(X_b * table), columns [H, H + L) are stored.
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64)
+                                                                : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
+k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const T* __restrict__ gtab,
+            const cplx<T>* __restrict__ tw_all, AolsGeom g, cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int P = 1 << LOGP, NT = P >> 4;
+  using F = ct::Fft<T, LOGP, 0, false>;
+  const unsigned seq = blockIdx.x >> 3;
+  const unsigned blk = (seq / unsigned(g.nrows)) * 8u + (blockIdx.x & 7u);
+  if (blk >= unsigned(g.nblocks)) return;
+  const RowDesc rd = rows[seq % unsigned(g.nrows)];
+  const int H = g.halo, L = P - 2 * H;
+  const cplx<T>* xb = xs + long(blk) * (P + 8);
+  const T* gt = gtab + rd.tab_off;
+  const long col0 = long(blk) * L, left = ncols - col0;
+  const int nlim = left < L ? int(left) : L;
+  cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  T re[16], im[16], gv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {                          // all loads first, then the arithmetic
+    const cplx<T> v = xb[f.j + e * NT];
+    re[e] = v.x; im[e] = v.y;
+    gv[e] = gt[f.j + e * NT];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { re[e] *= gv[e]; im[e] *= gv[e]; }
+  f.run(re, im, lds, tw_all + (P - 2));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int nl = f.j + e * NT - H;
+    if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+  }
+}
+
+// =============================================================================================
+// Band-limited rows in POLYNOMIAL form (k_poly_coef, k_poly_rows): no tile structure in the kernel that writes W.
+//
+// A row whose filter lives on the bins k_c + kappa, kappa in [-B/2, B/2), is a carrier times a slowly varying envelope:
+//     W[n] = e^{2 pi i k_c n / N} v(n),     v(n) = sum_kappa Y[kappa] e^{2 pi i kappa n / N},  Y = xhat F_j / N.
+// Cut the row into K' >= B intervals of R = N / K' samples: n = R m + r, u = (r - R/2) / (R/2) in [-1, 1).  Then
+//     e^{2 pi i kappa n / N} = e^{2 pi i kappa m / K'} e^{i pi kappa / K'} e^{i theta u},   theta = pi kappa / K'  (|theta| <= pi B / (2 K'))
+// and with e^{i theta u} = sum_d (i theta)^d u^d / d! cut at degree D
+//     v(R m + r) = sum_{d <= D} a_d[m] u^d,    a_d = IFFT_K'( Y[kappa] e^{i pi kappa / K'} (i theta)^d / d! ).
+// Stage 1 (k_poly_coef): D + 1 short inverse FFTs per row -> coefficient planes a_d[0 .. K'), a few per cent of the row's
+// bytes.  Stage 2 (k_poly_rows): every output is one Horner evaluation, one modulation and one contiguous non-temporal
+// store: a streaming kernel with many waves per CU and no FFT, which runs at the contiguous-store rate of the chip instead
+// of the 128-byte-segment rate of a K-point transform per residue.  What it must not do is start every wave with a fetch
+// of its own coefficients (latency bound, tools/microbench/stream_poly2.hip): a workgroup fetches the sets of all the
+// intervals it touches once, into LDS, and covers POLY_PASSES x 256 lanes x 16 bytes with them (stream_poly3.hip: 6.1 - 6.7
+// TB/s at two passes for R = 64 ... 4096, degree 8; one pass 3.4, four 5.8).
+// The host picks K' and D per row: D is the smallest even degree with  F(kappa)/F_max * |theta|^(D+1)/(D+1)! <= the support
+// threshold on every bin, i.e. the truncation is treated like the band limit itself.
+constexpr int POLY_MAX_CLASSES = 8;       // K' = 2^8 ... 2^14 + one spare
+constexpr int POLY_LOGP = 14;             // points per workgroup of k_poly_coef (1024 threads)
+constexpr int POLY_MAX_DEGREE = 24;
+constexpr int POLY_PASSES = 2;            // passes of 256 lanes x 16 bytes per workgroup of k_poly_rows
+constexpr int POLY_MIN_LOGR = 6;          // shortest interval: 64 samples
+struct PolyClass {
+  int logK;        // log2 K'
+  int row_first;   // first row of the class in the row table handed to the kernels
+  int nrows;
+  int ndeg;        // degrees computed per row of this class = 1 + the largest degree in it
+  int wg_first;    // first workgroup of the class in the k_poly_coef launch
+};
+struct PolyClasses {
+  PolyClass c[POLY_MAX_CLASSES];
+  int n;
+};
+
+// 1 / d!, d <= POLY_MAX_DEGREE
+__device__ __forceinline__ double inv_factorial(int d) {
+  constexpr double t[POLY_MAX_DEGREE + 1] = {
+      1.0, 1.0, 0.5, 1.6666666666666666e-01, 4.1666666666666664e-02, 8.3333333333333332e-03, 1.3888888888888889e-03,
+      1.9841269841269841e-04, 2.4801587301587302e-05, 2.7557319223985893e-06, 2.7557319223985888e-07,
+      2.5052108385441720e-08, 2.0876756987868100e-09, 1.6059043836821613e-10, 1.1470745597729725e-11,
+      7.6471637318198164e-13, 4.7794773323873853e-14, 2.8114572543455206e-15, 1.5619206968586226e-16,
+      8.2206352466243295e-18, 4.1103176233121648e-19, 1.9572941063391263e-20, 8.8967913924505741e-22,
+      3.8681701706306835e-23, 1.6117375710961184e-24};
+  return t[d];
+}
+
+// The filtered, phase-shifted band of every polynomial row in the input order of its K'-point transforms:
+//   yb[band_off + q] = Y[kappa(q)] e^{i pi kappa(q) / K'},  kappa(q) = the band bin congruent to q mod K' (0 if there is none)
+// -- computed once per row (one filter evaluation per bin), read by the D + 1 transforms of the row.  grid = (K'_max / 256, rows).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_poly_band(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo, TwN<T> twn, int logN,
+            cplx<T>* __restrict__ yb) {
+  const RowDesc rd = rows[blockIdx.y];
+  const int K = 1 << rd.logK, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= K) return;
+  const int N = 1 << logN;
+  const int kc = rd.k_lo + (rd.nband >> 1), klo = rd.k_lo - kc;
+  const int kap = klo + ((q - klo) & (K - 1));
+  const cplx<T> y = filtered_bin<T>(xhat, rd, mo, kc + kap, N - 1);        // 0 outside the band
+  const cplx<T> ph = twn((unsigned(kap) << (logN - rd.logK - 1)) & unsigned(N - 1));   // e^{2 pi i kappa (R/2) / N}
+  yb[rd.aux_off + q] = cmul<T>(y, ph);
+}
+
+// One workgroup = 2^(14 - LOGK) transforms of K' = 2^LOGK points, ROWS layout (lanes run along the interval index m, so the
+// planes are written in whole lines; K' <= 1024: a transform lives in one wavefront and needs no workgroup barrier).
+// Transform `job` of the class = (row, degree): job = row * ndeg + d; its input is the row's band times (i theta)^d / d!.
+template <typename T, int LOGK>
+__device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows,
+                                               const cplx<T>* __restrict__ tw_all, const PolyClass& pc,
+                                               unsigned local_wg, cplx<T>* __restrict__ coef, T* lds) {
+  constexpr int LOGTB = POLY_LOGP - LOGK, TB = 1 << LOGTB, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
+  using F = ct::Fft<T, LOGK, LOGTB, false>;
+  F f;
+  f.j = threadIdx.x & (NT - 1);
+  f.t = threadIdx.x >> LOGNT;
+  const int job = int(local_wg) * TB + f.t;
+  const int rowi = job / pc.ndeg, d = job - rowi * pc.ndeg;
+  RowDesc rd;
+  bool live = rowi < pc.nrows;
+  if (live) rd = rows[pc.row_first + rowi];
+  live = live && d <= rd.nterms;                              // nterms = the row's degree D
+  T re[16], im[16];
+  if (live) {
+    const cplx<T>* y = yb + rd.aux_off + f.j;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {                            // all loads first
+      const cplx<T> v = y[e * NT];
+      re[e] = v.x; im[e] = v.y;
+    }
+    const int klo = -(rd.nband >> 1);                         // kappa of the first band bin
+    const T tscale = T(3.14159265358979323846 / double(K));
+    const T ifact = T(inv_factorial(d));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = f.j + e * NT;
+      const int kap = klo + ((q - klo) & (K - 1));
+      const T pw = ipow<T>(T(kap) * tscale, d) * ifact;       // theta^d / d!
+      T vr = re[e] * pw, vi = im[e] * pw;
+      if (d & 1) { const T tmp = vr; vr = -vi; vi = tmp; }    // times i^d
+      if (d & 2) { vr = -vr; vi = -vi; }
+      re[e] = vr; im[e] = vi;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { re[e] = T(0); im[e] = T(0); }
+  }
+  f.run(re, im, lds, tw_all + (K - 2));
+  if (!live) return;
+  cplx<T>* out = coef + rd.tab_off + (long(d) << LOGK) + f.j;  // plane d of the row
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT] = mk<T>(re[e], im[e]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1 << (POLY_LOGP - 4), 4)
+k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ tw_all,
+            PolyClasses cls, cplx<T>* __restrict__ coef) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  PolyClass pc = cls.c[0];
+#pragma unroll
+  for (int i = 1; i < POLY_MAX_CLASSES; ++i)
+    if (i < cls.n && int(blockIdx.x) >= cls.c[i].wg_first) pc = cls.c[i];
+  const unsigned local = blockIdx.x - unsigned(pc.wg_first);
+#define CWT_POLY_CASE(LK) \
+  case LK: poly_coef_body<T, LK>(yb, rows, tw_all, pc, local, coef, lds); break;
+  switch (pc.logK) {
+    CWT_POLY_CASE(8) CWT_POLY_CASE(9) CWT_POLY_CASE(10) CWT_POLY_CASE(11) CWT_POLY_CASE(12) CWT_POLY_CASE(13)
+    CWT_POLY_CASE(14)
+    default: break;
+  }
+#undef CWT_POLY_CASE
+}
+
+// Stage 2.  One workgroup = 256 lanes x POLY_PASSES passes; a lane stores 16 bytes per pass (one complex128 or two adjacent
+// complex64 outputs).  sc[i][d] = a_d[m0 + i] for the intervals m0 ... the workgroup touches.
+template <typename T, int D>
+__device__ __forceinline__ void poly_rows_body(const RowDesc& rd, const cplx<T>* __restrict__ coef, const TwN<T>& twn,
+                                               int logN, cplx<T>* __restrict__ W, long ldw, long ncols, cplx<T>* sc) {
+  constexpr int PT = sizeof(T) == 8 ? 1 : 2, SPAN = 256 * PT, I = POLY_PASSES;
+  const int logR = logN - rd.logK;
+  const unsigned nmask = unsigned((1 << logN) - 1);
+  const unsigned n0 = blockIdx.x * unsigned(SPAN * I);
+  const unsigned m0 = n0 >> logR;
+  const unsigned last = (n0 + unsigned(SPAN * I) - 1u) & nmask;          // (the grid covers ncols <= N outputs)
+  const unsigned nint = ((last >= n0 ? last : nmask) >> logR) - m0 + 1u;
+  const cplx<T>* a = coef + rd.tab_off + m0;
+  for (unsigned t = threadIdx.x; t < nint * unsigned(D + 1); t += 256u) {
+    const unsigned i = t / unsigned(D + 1), d = t - i * unsigned(D + 1);
+    sc[t] = a[(long(d) << rd.logK) + i];
+  }
+  const int kc = rd.k_lo + (rd.nband >> 1);
+  const unsigned nl = n0 + threadIdx.x * PT;
+  cplx<T> w = twn((unsigned(kc) * nl) & nmask);
+  const cplx<T> step = twn((unsigned(kc) * unsigned(SPAN)) & nmask);    // uniform: one pass further
+  cplx<T> adj = mk<T>(T(1), T(0));
+  if constexpr (PT == 2) adj = twn(unsigned(kc) & nmask);                // e^{2 pi i k_c / N}: the lane's second output
+  const T scale = T(2) / T(1u << logR);
+  cplx<T>* wrow = W + long(rd.out_row) * ldw;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < I; ++p) {
+    const unsigned n = nl + unsigned(p * SPAN);
+    cplx<T> o[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const unsigned ni = n + unsigned(i);
+      const cplx<T>* c = sc + ((ni >> logR) - m0) * unsigned(D + 1);
+      const T u = T(int(ni & ((1u << logR) - 1u))) * scale - T(1);
+      T pr = c[D].x, pi = c[D].y;
+#pragma unroll
+      for (int d = D - 1; d >= 0; --d) { const cplx<T> cd = c[d]; pr = fma(pr, u, cd.x); pi = fma(pi, u, cd.y); }
+      const cplx<T> wi = i == 0 ? w : cmul<T>(w, adj);
+      o[i] = mk<T>(pr * wi.x - pi * wi.y, pr * wi.y + pi * wi.x);
+    }
+    if constexpr (PT == 1) {
+      if (long(n) < ncols) store_w<T>(wrow + n, o[0].x, o[0].y);
+    } else {
+      if (long(n) + 1 < ncols && ((reinterpret_cast<size_t>(wrow + n) & 15u) == 0)) {
+        typedef T vec4 __attribute__((vector_size(4 * sizeof(T))));
+        vec4 v = {o[0].x, o[0].y, o[PT - 1].x, o[PT - 1].y};
+        __builtin_nontemporal_store(v, reinterpret_cast<vec4*>(wrow + n));
+      } else {
+        if (long(n) < ncols) store_w<T>(wrow + n, o[0].x, o[0].y);
+        if (long(n) + 1 < ncols) store_w<T>(wrow + n + 1, o[PT - 1].x, o[PT - 1].y);
+      }
+    }
+    if (p + 1 < I) w = cmul<T>(w, step);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_poly_rows(const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ coef, TwN<T> twn, int logN,
+            cplx<T>* __restrict__ W, long ldw, long ncols) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  cplx<T>* sc = reinterpret_cast<cplx<T>*>(lds_raw);
+  const RowDesc rd = rows[blockIdx.y];
+#define CWT_POLYR_CASE(DD) case DD: poly_rows_body<T, DD>(rd, coef, twn, logN, W, ldw, ncols, sc); break;
+  switch (rd.nterms) {
+    CWT_POLYR_CASE(2) CWT_POLYR_CASE(4) CWT_POLYR_CASE(6) CWT_POLYR_CASE(8) CWT_POLYR_CASE(10) CWT_POLYR_CASE(12)
+    CWT_POLYR_CASE(14) CWT_POLYR_CASE(16) CWT_POLYR_CASE(18) CWT_POLYR_CASE(20) CWT_POLYR_CASE(22) CWT_POLYR_CASE(24)
+    default: break;
+  }
+#undef CWT_POLYR_CASE
 }
 
 // ---------------------------------------------------------------------------------------------
