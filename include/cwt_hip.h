@@ -110,17 +110,32 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
-/* Accuracy target of the transform: the bound, per row of W, on max|W - W_exact| / max|W_exact| that the fast forms
- * of the path may spend (W_exact = what wavelet.py:91-106 computes in exact arithmetic).  Three truncations are derived
- * from it: the filter support (bins of psi_ft below rel_tol/10 of its peak count as zero: band limiting), the
- * overlap-save halo (neglected L1 mass of |psi| <= rel_tol/10) and the "not clipped at Nyquist" test of the
- * overlap-save rows (profile at the Nyquist bins <= rel_tol of its peak).  0 selects the default: 1e-9 for
- * precision 64 and 3e-5 for precision 32 (measured worst-row errors 2e-10 and 5e-6: more than two orders of magnitude
- * inside the 1e-6 / 1e-3 parity bars of the path); 1e-16 makes every truncation smaller than fp64 rounding (results then agree with the reference to
- * ~3e-15).  Rounding of the arithmetic itself (~1e-15 / ~3e-6) comes on top.  Also reachable as the option
- * "tolerance_neglog10" (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces
- * the default of new plans (the test-suite sets 1e-16 where it checks the kernels' arithmetic).  Measured error and speed per target: profiles/r03_tolerance_sweep.txt. */
+/* Accuracy target of the fast forms.  Every row form of the path rests on truncations of the filter, and all of them are
+ * derived from this one number: the filter support (bins of psi_ft below rel_tol/10 of its largest value on the row's bins
+ * count as zero: band limiting), the overlap-save halo (neglected L1 mass of the wavelet <= rel_tol/10), the "not clipped
+ * at Nyquist" test of the overlap-save rows (profile at the Nyquist bins <= rel_tol of its peak) and the degree of the
+ * polynomial rows (Taylor remainder of a bin, weighted by the filter's value there, <= rel_tol/10).
+ * What the number bounds: the truncations are relative to the FILTER, so for a signal whose spectrum is flat (white noise:
+ * max|xhat| / rms|xhat| ~ 4) the error of a row relative to its own peak, max|W - W_exact| / max|W_exact|, stays below
+ * rel_tol (measured: 2e-10 at 1e-9, 5e-6 at 3e-5, N = 2^20); for a spectrum with dynamic range D = max|xhat| / rms|xhat|
+ * it can reach rel_tol * D / 4 (a line 1e4 above the noise floor: 1.5e-5 at rel_tol = 1e-9, 6e-11 at 1e-16; D is meant against
+ * the quietest part of the spectrum, see cwt_spectrum_range) -- it is NOT a
+ * signal-independent bound.  Hence the default (rel_tol = 0) is round-off: 1e-16 for precision 64, 1e-8 for precision 32,
+ * every truncation below the arithmetic's own rounding (~3e-15 / ~2e-6 against the reference), for any input.  Callers that
+ * know their spectra pass a looser target and get the faster forms (bench.py: 1e-9 / 3e-5 on white noise; error and speed
+ * per target: profiles/r04_tolerance_sweep.txt); callers that do not can measure D (cwt_spectrum_range) or let
+ * cwt_execute_host do it per call (cwt_plan_set_auto_tolerance).  Also reachable as the option "tolerance_neglog10"
+ * (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces the default of new plans. */
 int cwt_plan_set_tolerance(cwt_plan* plan, double rel_tol);
+/* target > 0: cwt_execute_host (the host-buffer call, which synchronises anyway) sets the plan's tolerance per call to
+ * target * min(1, 6 / D), D = max|xhat| / (rms of the quietest octave of the spectrum) of that call, rounded down to a
+ * power of ten and never below round-off -- the accuracy target then holds relative to every row's own peak for spectra of
+ * any dynamic range (lines, red noise).  0 = off (the plan's own tolerance is used).  The device-resident entry points
+ * never synchronise and never do this. */
+int cwt_plan_set_auto_tolerance(cwt_plan* plan, double target);
+/* Of a device-resident spectrum of n bins (one small kernel + a synchronising copy): max|xhat[k]|, rms|xhat[k]| and the rms
+ * of the quietest octave [2^b, 2^(b+1)) of the positive half that has at least 64 bins (the rms itself for n < 256). */
+int cwt_spectrum_range(cwt_plan* plan, const void* xhat_dev, int64_t n, double* max_abs, double* rms_abs, double* floor_abs);
 int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 /* Block the host until everything queued by this plan has finished. */
 int cwt_plan_sync(cwt_plan* plan);

@@ -78,6 +78,8 @@ SYMBOLS = [
     ("cwt_shard_cost", C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     ("cwt_plan_set_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_plan_get_tolerance", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("cwt_plan_set_auto_tolerance", C.c_int, [_P, C.c_double]),
+    ("cwt_spectrum_range", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 
 
@@ -179,6 +181,8 @@ class Plan:
         for k, v in (options or {}).items():
             if k == "tolerance":
                 self.set_tolerance(v)
+            elif k == "auto_tolerance":
+                self.set_auto_tolerance(v)
             else:
                 self.set_option(k, v)
 
@@ -204,6 +208,19 @@ class Plan:
     def set_tolerance(self, rel_tol: float):
         """Accuracy target per row of W (max|dW| / max|W|); 0 = the precision's default (see cwt_plan_set_tolerance)."""
         self.lib.check(self.lib.cwt_plan_set_tolerance(self.h, float(rel_tol)))
+
+    @_locked
+    def set_auto_tolerance(self, target: float):
+        """execute_host() derives each call's tolerance from `target` and the dynamic range of the call's spectrum
+        (cwt_plan_set_auto_tolerance); 0 = off."""
+        self.lib.check(self.lib.cwt_plan_set_auto_tolerance(self.h, float(target)))
+
+    @_locked
+    def spectrum_range(self, xhat_dev: int, n: int):
+        """(max|xhat|, rms|xhat|, rms of the quietest octave) of a device-resident spectrum."""
+        mx, rms, fl = C.c_double(0), C.c_double(0), C.c_double(0)
+        self.lib.check(self.lib.cwt_spectrum_range(self.h, _P(xhat_dev), n, C.byref(mx), C.byref(rms), C.byref(fl)))
+        return mx.value, rms.value, fl.value
 
     @_locked
     def tolerance(self) -> float:

@@ -214,6 +214,10 @@ struct cwt_plan {
   // Accuracy target of a row, max|dW| / max|W| against the exact transform (cwt_plan_set_tolerance; 0 = the precision's
   // default).  The three truncations of the fast forms are derived from it (see tolerances()).
   double tolerance = 0.0;
+  double auto_target = 0.0;   // > 0: cwt_execute_host derives the tolerance of each call from this target and the measured
+                              // dynamic range of the call's spectrum (cwt_plan_set_auto_tolerance)
+  double last_range = 0.0;    // max|xhat| / rms|xhat| of the last such call
+  double* range_dev = nullptr;
   // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
   unsigned long long* stamps = nullptr;
   int64_t stamp_cap = 0, stamp_next = 0;
@@ -311,9 +315,11 @@ struct cwt_plan {
 
 namespace {
 
-// Default accuracy targets: three orders of magnitude inside the parity bars of the path (1e-6 relative in fp64, 1e-3 in
-// fp32); the measured worst-row errors per target are in profiles/r03_tolerance_sweep.txt.
-constexpr double kDefaultTolerance64 = 1e-9, kDefaultTolerance32 = 3e-5;
+// Default accuracy targets: every truncation of the fast forms below the arithmetic's own rounding.  The truncations are
+// relative to the FILTER's peak, so the error they leave relative to a row's own peak grows with the dynamic range of the
+// signal's spectrum; a caller that knows its spectra (bench.py: white noise) or measures them (cwt_spectrum_range; the
+// automatic mode of cwt_execute_host, cwt_plan_set_auto_tolerance) passes a looser target and gets the faster forms.
+constexpr double kDefaultTolerance64 = 1e-16, kDefaultTolerance32 = 1e-8;
 // The truncations that make the fast forms possible, all derived from the one accuracy target tol of the plan:
 //   support  bins whose profile is below this fraction of its peak are treated as exactly zero (band limiting);
 //   halo     neglected fraction of the L1 mass of |psi| beyond the overlap-save halo (a bound on the relative error);
@@ -536,17 +542,24 @@ double host_aols_window(const AolsGeom& g, double f) {
 
 // Smallest halo H (multiple of 64, <= hmax) beyond which the kernel e = IFFT(E), E(f) = G(aN f) u(f), carries less than
 // eps of its L1 mass -- the bound on the relative error of an output sample, as for the overlap-save rows on the real
-// signal -- or 0 if there is none.  e is evaluated numerically on a 4 hmax-point grid (its wrap-around beyond 2 hmax
+// signal -- or 0 if there is none or if the row does not qualify (see below).  e is evaluated numerically on a 4 hmax-point grid (its wrap-around beyond 2 hmax
 // samples is far below eps for every row that passes).
 int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps, int hmax) {
   const int n = 4 * hmax;
   std::vector<std::complex<double>> e(size_t(n), std::complex<double>(0.0, 0.0));
   const int k0 = int(std::ceil(g.f_s * n));
+  double in_band = 0, beyond = 0;
   for (int q = 0; q < n; ++q) {
     const int kappa = k0 + (((q - k0) % n) + n) % n;
     const double f = double(kappa) / double(n);
-    e[size_t(q)] = host_profile(mother, param, aN * f) * host_aols_window(g, f);
+    const double v = host_profile(mother, param, aN * f) * host_aols_window(g, f);
+    e[size_t(q)] = v;
+    (f <= 0.5 ? in_band : beyond) = std::max(f <= 0.5 ? in_band : beyond, std::fabs(v));
   }
+  // A profile that keeps RISING past Nyquist (its peak lies beyond pi / dt: scales below the mother's own Nyquist limit)
+  // would make the tapered continuation larger than the filter itself: exact arithmetic never sees it (x_M has nothing
+  // there), rounding noise of the block spectra does, amplified by that ratio.  Such rows keep the N-point transform.
+  if (!(beyond <= 2.0 * in_band)) return 0;
   host_ifft(e);
   std::vector<double> ring(size_t(n / 2) + 1, 0.0);                 // |e| by distance from t = 0
   double total = 0;
@@ -685,7 +698,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows, poly_rows;
   std::vector<char> wide_clipped;
   const bool poly_ok = p->poly && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && mother != MOTHER_TABLE &&
-                       p->logN >= std::max(POLY_LOGP, p->poly_min_logn) && !use_small;
+                       p->logN >= std::max(POLY_LOGP, p->poly_min_logn) && !use_small && rows_per_signal == 0;   // (not for batches yet)
   struct OlsRow { RowDesc rd; int grp, lb, h64; };
   std::vector<OlsRow> ols_rows;
   for (int j = 0; j < nrows; ++j) {
@@ -915,7 +928,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   };
   std::stable_sort(narrow_rows.begin(), narrow_rows.end(),
                    [&](const RowDesc& x, const RowDesc& y) { return group_key(x) < group_key(y); });
-  if (p->narrow_mix) {
+  if (p->narrow_mix && p->use_ct && logP == (p->prec == 64 ? 13 : 14)) {   // (the generic kernels launch per (K, terms) group)
     // Launch order inside k_narrow_ct_all: the rows are sorted light (K = 16: store bound) to heavy (K = 1024 with three
     // terms: the longest compute phase); consecutive rows share the CUs, so alternate the two ends of the list -- a CU's two
     // tile slots then hold one store-heavy and one compute-heavy tile instead of two of a kind.  (Complex64: the rows
@@ -2061,7 +2074,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->hx, p->hxhat, p->hW, p->stamps,
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->range_dev, p->hx, p->hxhat, p->hW, p->stamps,
                   p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
@@ -2174,6 +2187,44 @@ int cwt_plan_set_tolerance(cwt_plan* p, double rel_tol) {
   if (!(rel_tol >= 0) || rel_tol > 1e-2) return fail(CWT_EINVAL, "tolerance must be in [0, 1e-2] (0 = default)");
   for (auto& t : p->slots) t.key.clear();   // the classification depends on it
   p->tolerance = rel_tol;
+  return CWT_OK;
+}
+
+int cwt_plan_set_auto_tolerance(cwt_plan* p, double target) {
+  if (!p) return fail(CWT_EINVAL, "plan is NULL");
+  if (!(target >= 0) || target > 1e-2) return fail(CWT_EINVAL, "target must be in [0, 1e-2] (0 = off)");
+  p->auto_target = target;
+  return CWT_OK;
+}
+
+int cwt_spectrum_range(cwt_plan* p, const void* xhat_dev, int64_t n, double* max_abs, double* rms_abs, double* floor_abs) {
+  if (!p || !xhat_dev || !max_abs || !rms_abs || !floor_abs) return fail(CWT_EINVAL, "NULL argument");
+  if (n < 1) return fail(CWT_EINVAL, "n must be >= 1");
+  HIPCHECK(hipSetDevice(p->device));
+  constexpr int kOut = 2 + SPECTRUM_OCTAVES;
+  if (!p->range_dev && hipMalloc(reinterpret_cast<void**>(&p->range_dev), kOut * sizeof(double)) != hipSuccess)
+    return fail(CWT_ENOMEM, "device allocation failed");
+  if (p->prec == 64)
+    hipLaunchKernelGGL((k_spectrum_range<double>), dim3(1), dim3(1024), 1024 * sizeof(double), p->stream,
+                       static_cast<const double2*>(xhat_dev), long(n), p->range_dev);
+  else
+    hipLaunchKernelGGL((k_spectrum_range<float>), dim3(1), dim3(1024), 1024 * sizeof(double), p->stream,
+                       static_cast<const float2*>(xhat_dev), long(n), p->range_dev);
+  HIPCHECK(hipGetLastError());
+  double h[kOut] = {0};
+  HIPCHECK(hipMemcpyAsync(h, p->range_dev, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+  HIPCHECK(hipStreamSynchronize(p->stream));
+  *max_abs = std::sqrt(h[0]);
+  *rms_abs = std::sqrt(h[1] / double(n));
+  // the quietest octave of the positive half with at least 64 bins (shorter ones fluctuate too much); short spectra: the rms
+  double fl = -1;
+  for (int b = 6; b < SPECTRUM_OCTAVES; ++b) {
+    const int64_t lo = int64_t(1) << b, hi = std::min<int64_t>(lo * 2, n / 2);
+    if (hi - lo < 64) continue;
+    const double r = std::sqrt(h[2 + b] / double(hi - lo));
+    if (fl < 0 || r < fl || r != r) fl = r;
+  }
+  *floor_abs = fl >= 0 ? fl : *rms_abs;
   return CWT_OK;
 }
 
@@ -2872,6 +2923,25 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!rc && W_host) rc = grow(&p->hW, &p->hW_bytes, size_t(nrows) * size_t(n0) * 2 * es, p->stream);
   if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(p->hx, x_host, size_t(n0) * es, hipMemcpyHostToDevice, p->stream));
+  if (W_host && p->auto_target > 0) {
+    // accuracy target of THIS call = auto_target / (dynamic range of its spectrum relative to white noise), a power of
+    // ten (so that calls with like spectra share one cached row table), never looser than the target itself
+    rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
+    double mx = 0, rms = 0, fl = 0;
+    if (!rc) rc = cwt_spectrum_range(p, p->hxhat, p->N, &mx, &rms, &fl);
+    if (rc) return rc;
+    double tol = p->auto_target;
+    if (fl > 0 && std::isfinite(mx)) {
+      p->last_range = mx / fl;
+      const double excess = p->last_range / 6.0;           // white noise: max / quietest octave ~ 4 ... 5
+      if (excess > 1.0) tol = std::pow(10.0, std::floor(std::log10(p->auto_target / excess)));
+    } else if (!(fl > 0)) {
+      tol = 0.0;                                            // an empty octave (or a non-finite spectrum): round-off
+    }
+    const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
+    tol = std::max(tol, floor_tol);
+    if (tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = tol; }
+  }
   if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);
   else rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
   if (rc) return rc;

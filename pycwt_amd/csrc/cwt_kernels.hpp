@@ -1930,6 +1930,43 @@ __global__ void k_coherence_hist(const T* __restrict__ R2, long ld, const long* 
     if (h[b]) atomicAdd(&hist[long(row) * nbins + b], (unsigned long long)h[b]);
 }
 
+// k_spectrum_range: out[0] = max_k |xhat[k]|^2, out[1] = sum_k |xhat[k]|^2 over the n bins, out[2 + b] = the sum over the
+// octave b of the positive half, 2^b <= k < min(2^(b+1), n/2) (one workgroup, fp64 accumulation): the dynamic range of the
+// spectrum, by which a caller divides the accuracy it wants (cwt_spectrum_range).
+constexpr int SPECTRUM_OCTAVES = 32;
+template <typename T>
+__global__ void k_spectrum_range(const cplx<T>* __restrict__ xhat, long n, double* __restrict__ out) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  double* part = reinterpret_cast<double*>(lds_raw);       // [0, bd): scratch of one reduction
+  double mx = 0, sm = 0, oct[SPECTRUM_OCTAVES];
+  for (int b = 0; b < SPECTRUM_OCTAVES; ++b) oct[b] = 0;
+  for (long k = threadIdx.x; k < n; k += blockDim.x) {
+    const cplx<T> v = xhat[k];
+    const double a = double(v.x) * double(v.x) + double(v.y) * double(v.y);
+    mx = a > mx || a != a ? a : mx;                         // NaN propagates
+    sm += a;
+    if (k >= 1 && k < n / 2) {
+      int b = 0;
+      while ((2L << b) <= k) ++b;                           // floor(log2 k)
+      oct[b] += a;
+    }
+  }
+  for (int q = 0; q < 2 + SPECTRUM_OCTAVES; ++q) {
+    part[threadIdx.x] = q == 0 ? mx : q == 1 ? sm : oct[q - 2];
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+      if (int(threadIdx.x) < s) {
+        const double o = part[threadIdx.x + s];
+        if (q == 0) { if (o > part[threadIdx.x] || o != o) part[threadIdx.x] = o; }
+        else part[threadIdx.x] += o;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = part[0];
+    __syncthreads();
+  }
+}
+
 // k_time_mean: out[j] = (1/ncols) sum_n |W[j, n]|^2  -- the global wavelet spectrum (power.mean(axis=1),
 // sample/simple_sample.py:79).  One workgroup of 256 threads per row, fp64 accumulation.
 template <typename T>

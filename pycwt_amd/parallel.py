@@ -111,6 +111,8 @@ class HipEngine:
             self.plan.transform(x.data_ptr(), n0, kind, param, dt, sj, None if xhat is None else xhat.data_ptr(),
                                 W.data_ptr(), W.shape[-1], ncols)
         else:                                             # a batch: cwt_transform_batch (spectra to xhat, required)
+            if xhat is None:
+                xhat = self.torch.empty((x.shape[0], self.plan.nfft), dtype=W.dtype, device=W.device)
             self.plan.transform_batch(x.data_ptr(), x.shape[0], x.shape[1], n0, kind, param, dt, sj, xhat.data_ptr(),
                                       W.data_ptr(), W.shape[-1], ncols)
 
@@ -165,7 +167,11 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
     N = _next_pow2(n0)
     bad = _nan_rows(mother, sj, N, dt)
-    if bad.any() and not bad.all():
+    # a NaN / inf sample makes every row NaN in the reference (wavelet.py:91), which then keeps all rows (:111-115); the
+    # block-wise rows of cwt_transform would confine the damage, so such signals go through the spectrum-only entry points
+    # (as pycwt_amd.cwt does).  Every rank holds the broadcast signal and decides alike.
+    finite = bool(torch.isfinite(x).all().item())
+    if bad.any() and not bad.all() and finite:
         sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
     coi = _coi(mother, n0, dt)
 
@@ -187,7 +193,7 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     else:
         mine = shard_rows(sj.size, world, rank)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)
-    if hasattr(engine, "transform"):
+    if hasattr(engine, "transform") and finite:
         if mine.size:                                     # one signal: the spectrum stays inside the library
             xhat = torch.empty(shape[:-1] + (N,), dtype=cplx_t, device=device) if nbatch > 1 else None
             engine.transform(x, n0, xhat, kind, param, dt, np.ascontiguousarray(sj[mine]), W, n0)

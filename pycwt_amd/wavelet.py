@@ -29,19 +29,45 @@ _plans_lock = threading.Lock()
 PLAN_OPTIONS: dict = {}
 
 
-def set_tolerance(rel_tol=None):
-    """Accuracy target of every transform of this module from now on: the bound, per row of W, on
-    max|W - W_reference| / max|W_reference| that the engine's fast forms may spend (`cwt_plan_set_tolerance`).
-    None / 0 = the engine's default (1e-9 for complex128, 3e-5 for complex64: measured worst-row errors 2e-10 / 5e-6
-    at N = 2^20); 1e-16 = every truncation below fp64 rounding."""
+# Accuracy of the engine's fast forms (cwt_plan_set_tolerance).  "auto" (the default): the target below holds relative
+# to every row's own peak for signals of any spectral shape -- each transform measures the dynamic range of its spectrum
+# (max|xhat| / rms|xhat|, one small reduction on the GPU) and tightens the engine's filter-relative tolerance by it; a
+# float = that tolerance for every call (1e-16: every truncation below fp64 rounding); None = the engine's own default
+# (round-off).  The environment variable CWT_TOLERANCE (read by the engine) overrides "auto".
+AUTO_TARGET = {64: 1e-9, 32: 3e-5}
+_tolerance = "auto"
+
+
+def _auto(plan):
+    """The automatic mode's target for this plan, or 0.0 when a fixed tolerance is in force."""
+    if _tolerance == "auto" and not os.environ.get("CWT_TOLERANCE") and "tolerance" not in PLAN_OPTIONS:
+        return AUTO_TARGET[plan.precision]
+    return 0.0
+
+
+def _apply_tolerance(plan):
+    if _tolerance == "auto":
+        plan.set_auto_tolerance(_auto(plan))
+    else:
+        plan.set_auto_tolerance(0.0)
+        plan.set_tolerance(float(_tolerance or 0.0))
+
+
+def set_tolerance(rel_tol="auto"):
+    """Accuracy target of every transform of this module from now on.
+
+    "auto" (default): max|W - W_reference| / max|W_reference| <= 1e-9 per row (3e-5 in complex64) for ANY signal: the
+    engine's truncations are relative to the filter, so each call divides the target by the measured dynamic range of its
+    spectrum (`cwt_plan_set_auto_tolerance` / `cwt_spectrum_range`).  A float: the engine's filter-relative tolerance
+    itself, for every call (`cwt_plan_set_tolerance`; 1e-16 = every truncation below fp64 rounding).  None / 0: the
+    engine's default, round-off."""
+    global _tolerance
     with _plans_lock:
-        if rel_tol:
-            PLAN_OPTIONS["tolerance"] = float(rel_tol)
-        else:
-            PLAN_OPTIONS.pop("tolerance", None)
+        _tolerance = rel_tol if rel_tol else None
+        PLAN_OPTIONS.pop("tolerance", None)
         for plan in _plans.values():
             if plan.h:
-                plan.set_tolerance(float(rel_tol or 0.0))
+                _apply_tolerance(plan)
 
 
 def _check_parameter_wavelet(wavelet):
@@ -67,6 +93,8 @@ def _plan(nfft: int, precision: int, device: int, rows: int) -> _hip.Plan:
         plan = _plans.get(key)
         if plan is None or plan.max_rows < rows:
             plan = _hip.Plan(nfft, precision, max_rows=max(1024, rows), device=device, options=dict(PLAN_OPTIONS))
+            if "tolerance" not in PLAN_OPTIONS:
+                _apply_tolerance(plan)
             _plans[key] = plan
         return plan
 
@@ -91,6 +119,16 @@ def _transform(plan, x_host, xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr):
     drop-in, such signals go through the spectrum-only entry points (`cwt_forward_fft` + `cwt_transform_rows`, which
     never use the overlap-save form); the O(N) host scan is free next to the PCIe transfer of W."""
     if np.isfinite(x_host).all():
+        target = _auto(plan)
+        if target:      # automatic accuracy: the tolerance of this call from the dynamic range of its spectrum
+            plan.forward_fft(xd_ptr, n0, xh_ptr)
+            mx, _, floor = plan.spectrum_range(xh_ptr, plan.nfft)
+            tol = target
+            if not floor > 0:
+                tol = 0.0
+            elif np.isfinite(mx) and mx / floor > 6.0:
+                tol = 10.0 ** np.floor(np.log10(target * 6.0 * floor / mx))
+            plan.set_tolerance(max(tol, 1e-16 if plan.precision == 64 else 1e-8))
         plan.transform(xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr, n0, n0)
     else:
         plan.forward_fft(xd_ptr, n0, xh_ptr)
@@ -234,6 +272,17 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
     """
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
+    if np.iscomplexobj(signal):
+        # wavelet.py:91 transforms a complex signal as it is; the engine's forward transform is real-input, and the whole
+        # path is linear: W(x) = W(Re x) + i W(Im x), likewise the spectrum of the 5th return value
+        z = np.asarray(signal)
+        a = cwt(z.real, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
+        b = cwt(z.imag, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
+        fft5 = a[4] + 1j * b[4]
+        if z.dtype == np.complex64:
+            fft5 = fft5.astype(np.complex64)            # scipy.fftpack keeps single precision (wavelet.py:91, :123-124)
+        return (a[0] + 1j * b[0], a[1], a[2], a[3], fft5, a[5])
+    in_dtype = getattr(signal, "dtype", None)
     n0 = len(signal)
     sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
 
@@ -256,6 +305,10 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
             freqs = np.asarray(freqs)[keep]
         kind, param = mother.device_id()
         W, xhat = _cwt_builtin(x, dt, sj, kind, param, N, precision, device)
+        if bad.all():
+            # every row carries a NaN in its filter (Paul, all scales beyond the overflow of exp(-f)): the reference keeps
+            # all rows then (wavelet.py:112) and every one of them is NaN throughout
+            W = np.full(W.shape, complex(np.nan, np.nan), dtype=W.dtype)
     else:
         W, xhat, keep = _cwt_with_host_filter_bank(np.asarray(signal, dtype=real), dt, sj, mother, N, precision,
                                                    device)
@@ -268,7 +321,10 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
 
     coi = _coi(mother, n0, dt)
     ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)                 # wavelet.py:94
-    return (W, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi))
+    fft5 = xhat[1:N // 2] / N ** 0.5
+    if in_dtype == np.float32:
+        fft5 = fft5.astype(np.complex64)        # the reference's FFT of a float32 signal is complex64 (wavelet.py:91, :123-124)
+    return (W, sj, freqs, coi, fft5, ftfreqs[1:N // 2] / (2 * np.pi))
 
 
 class DeviceTransform:

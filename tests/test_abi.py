@@ -53,6 +53,7 @@ def test_torch_runtime_is_loaded_before_the_library():
     before it opens libcwt_hip.so; PYCWT_AMD_NO_TORCH_PRELOAD=1 skips that."""
     import subprocess
     import sys
+    pytest.importorskip("torch")          # nothing to order on a machine without torch
     code = ("import sys; sys.path.insert(0, %r); from pycwt_amd import _hip; assert 'torch' not in sys.modules; "
             "_hip._one_hip_runtime(); print('torch' in sys.modules)" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip()

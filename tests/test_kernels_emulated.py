@@ -141,7 +141,7 @@ def test_pass_a_classes_at_full_size(emu_library, kind, param, scales):
     m = orc.Mother(kind, param)
     sj = np.array(scales)
     ref = orc.cwt_rows(x, 1.0, sj, m)[:, :x.size]
-    for opts in ({"narrow_big": 0, "ols": 0}, {"narrow_big": 0, "band_pass_a": 0, "ols": 0}):
+    for opts in ({"narrow_big": 0, "ols": 0, "poly": 0}, {"narrow_big": 0, "band_pass_a": 0, "ols": 0, "poly": 0}):
         plan = _hip.Plan(N, 64, max_rows=4, lib=emu_library, options=opts)
         W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
         assert plan.last_split()["two_pass"] == len(scales)
@@ -267,7 +267,7 @@ def test_overlap_save_rows(emu_library, kind, param, prec, N, n0, rows):
         plan.close()
     W, split, classes = out[1]
     assert split["ols"] >= 4 and out[0][1]["ols"] == 0, (split, out[0][1])
-    assert split["ols"] + split["narrow"] + split["two_pass"] == len(sj)
+    assert split["ols"] + split["narrow"] + split["two_pass"] + split["aols"] + split["poly"] == len(sj)
     per_row, _ = row_errors(W, ref)
     assert per_row.max() < TOL[prec], (per_row.argmax(), per_row.max(), classes[per_row.argmax()])
     mine = [i for i, c in enumerate(classes) if c.startswith("ols/")]
@@ -328,7 +328,7 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
     x = np.random.default_rng(8).standard_normal(N - 77)
     m = orc.Mother(kind, param)
     sj = grid(x.size, 1.0, m, 72)
-    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=dict(opts, ols_min_logn=15))
+    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=dict(opts, ols_min_logn=15, poly=0))
     W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
     split, classes = plan.last_split(), plan.row_classes()
     plan.close()
@@ -356,7 +356,7 @@ def test_launch_order_of_the_band_limited_rows_does_not_change_a_bit(emu_library
     sj = grid(x.size, 1.0, m, 80)
     out = []
     for mix in (0, 1):
-        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"narrow_mix": mix, "ols_min_logn": 15})
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options={"narrow_mix": mix, "ols_min_logn": 15, "poly": 0})
         W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
         assert plan.last_split()["narrow"] >= 30
         plan.close()

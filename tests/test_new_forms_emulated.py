@@ -1,0 +1,164 @@
+"""The two row forms of round 4 on the CPU emulation of the HIP runtime (tests/emu), against the oracle and against the
+library's own older kernels:
+
+* polynomial rows (k_poly_band / k_poly_coef / k_poly_rows): band-limited rows as K' intervals of a degree-D polynomial
+  times a carrier;
+* rows clipped at the Nyquist bins as overlap-save rows on the band-passed complex signal (k_aols_*).
+
+The suite default (conftest: CWT_TOLERANCE = 1e-16) puts every truncation at round-off; the tests that pass a target check
+the error against that target.
+"""
+import numpy as np
+import pytest
+
+from conftest import row_errors
+from oracle import cwt_oracle as orc
+from pycwt_amd import _hip
+from test_kernels_emulated import TOL, grid
+
+
+def transform(lib, N, x, kind, param, sj, prec, opts, with_signal=True):
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    plan = _hip.Plan(N, prec, max_rows=len(sj), lib=lib, options=opts)
+    if with_signal:
+        W, _ = plan.execute_host(x, kind, param, 1.0, sj, want_xhat=False)
+    else:
+        es = np.dtype(real).itemsize
+        xd, xh = _hip.DeviceBuffer(x.size * es, lib=lib), _hip.DeviceBuffer(2 * es * N, lib=lib)
+        Wd = _hip.DeviceBuffer(2 * es * len(sj) * x.size, lib=lib)
+        xd.upload(plan, x.astype(real))
+        plan.forward_fft(xd.ptr, x.size, xh.ptr)
+        plan.transform_rows(xh.ptr, kind, param, 1.0, sj, Wd.ptr, x.size, x.size)
+        W = Wd.download(plan, (len(sj), x.size), cplx)
+        for b in (xd, xh, Wd):
+            b.free()
+    out = (W, plan.last_split(), plan.row_classes())
+    plan.close()
+    return out
+
+
+@pytest.mark.parametrize("kind,param,prec,logn,n0_off,rows", [
+    (orc.MORLET, 6, 64, 16, 0, 96),
+    (orc.MORLET, 6, 64, 16, 37, 64),          # ragged: the last workgroups of a row store a part of their span
+    (orc.MORLET, 6, 32, 16, 1, 64),           # complex64: two outputs per lane, an odd number of columns
+    (orc.DOG, 6, 64, 15, 0, 48),              # (the Paul rows the reference keeps are all too wide for the form: B > N / 64)
+    (orc.DOG, 2, 32, 16, 100, 64),
+    (orc.DOG, 3, 64, 15, 5, 40),              # odd order: imaginary mother constant
+    (orc.MORLET, 6, 64, 17, 1000, 40),
+])
+def test_polynomial_rows(emu_library, kind, param, prec, logn, n0_off, rows):
+    """Band-limited rows in polynomial form against the oracle (at round-off: the suite's accuracy target) and against the
+    same rows through the transform-per-residue kernels (option poly = 0)."""
+    N = 1 << logn
+    n0 = N - n0_off
+    x = np.random.default_rng(31).standard_normal(n0)
+    m = orc.Mother(kind, param)
+    sj = grid(n0, 1.0, m, rows)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
+    W, split, classes = transform(emu_library, N, x, kind, param, sj, prec, {"poly_min_logn": 14})
+    assert split["poly"] >= len(sj) // 3, split
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < 3 * TOL[prec], (per_row.argmax(), per_row.max(), classes[per_row.argmax()])
+    W0, split0, _ = transform(emu_library, N, x, kind, param, sj, prec, {"poly": 0})
+    assert split0["poly"] == 0
+    mine = [i for i, c in enumerate(classes) if c.startswith("poly/")]
+    assert row_errors(W[mine], W0[mine])[0].max() < 3 * TOL[prec]
+    # from the spectrum alone (cwt_transform_rows) the same rows take the form
+    W1, split1, classes1 = transform(emu_library, N, x, kind, param, sj, prec, {"poly_min_logn": 14}, with_signal=False)
+    assert split1["poly"] >= split["poly"]
+    assert row_errors(W1, ref)[0].max() < 3 * TOL[prec]
+
+
+@pytest.mark.parametrize("prec,target,bar", [(64, 1e-9, 1e-9), (64, 1e-6, 1e-6), (32, 3e-5, 3e-5)])
+def test_polynomial_rows_follow_the_accuracy_target(emu_library, prec, target, bar):
+    """A looser target means fewer intervals or lower degrees; the error stays inside the target."""
+    N = 1 << 16
+    x = np.random.default_rng(4).standard_normal(N)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 80)[30:]
+    ref = orc.cwt_rows(x, 1.0, sj, m)
+    W, split, classes = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"tolerance": target, "poly_min_logn": 14})
+    Wt, _, tight = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_min_logn": 14})
+    assert split["poly"] > 20
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < bar, (per_row.max(), classes[per_row.argmax()])
+
+    def cost(labels):
+        return sum(int(c.split("/")[1][1:]) * (int(c.split("/")[2][1:]) + 1) for c in labels if c.startswith("poly/"))
+    assert cost(classes) < cost(tight)
+
+
+def test_polynomial_rows_with_a_strong_spectral_line(emu_library):
+    """The truncation rule weighs a bin's Taylor remainder by the filter's value there, like the support threshold: both are
+    relative to the FILTER's peak, so a spectral line far above the rest of the spectrum (here 1e4 x the noise: a dynamic
+    range of 1.3e6 in |xhat|) raises the error relative to the row's own peak by that range -- 1e-17 x 1.3e6 at the
+    round-off target.  The target a caller wants must be divided by the spectral dynamic range (pycwt_amd.cwt does)."""
+    N = 1 << 16
+    n = np.arange(N)
+    x = np.random.default_rng(9).standard_normal(N) + 1e4 * np.cos(2 * np.pi * 300 * n / N)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 80)[30:70]
+    ref = orc.cwt_rows(x, 1.0, sj, m)
+    W, split, classes = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"poly_min_logn": 14})
+    assert split["poly"] > 20
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < 1e-10, (per_row.max(), classes[per_row.argmax()])
+
+
+@pytest.mark.parametrize("kind,param,prec,logn,n0_off,rows", [
+    (orc.MORLET, 6, 64, 15, 0, 48),           # circular edges
+    (orc.MORLET, 6, 64, 16, 4099, 64),        # padded signal, ragged last block
+    (orc.MORLET, 5, 64, 15, 1, 40),           # lower f0: the mask reaches further into the negative frequencies
+    (orc.PAUL, 4, 32, 16, 77, 96),
+    (orc.PAUL, 2, 32, 15, 0, 48),             # slow t^-3 tails: long halos or no row at all
+    (orc.MORLET, 6, 32, 15, 11, 48),
+])
+def test_rows_clipped_at_nyquist_on_the_band_passed_signal(emu_library, kind, param, prec, logn, n0_off, rows):
+    """The smallest scales (filter cut at the Nyquist bins) as overlap-save rows on x_M = IFFT(xhat * mask): against the
+    oracle and against the two-pass rows they replace (option aols = 0)."""
+    N = 1 << logn
+    n0 = N - n0_off
+    x = np.random.default_rng(17).standard_normal(n0)
+    m = orc.Mother(kind, param)
+    sj = grid(n0, 1.0, m, rows)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
+    opts = {"ols_min_logn": 15, "poly": 0}
+    W, split, classes = transform(emu_library, N, x, kind, param, sj, prec, opts)
+    W0, split0, classes0 = transform(emu_library, N, x, kind, param, sj, prec, dict(opts, aols=0))
+    assert split0["aols"] == 0 and split0["two_pass"] >= 3
+    if (kind, param) != (orc.PAUL, 2):
+        assert split["aols"] >= 3 and split["two_pass"] < split0["two_pass"], (split, split0)
+    bar = 20 * TOL[prec] if prec == 64 else TOL[prec]          # fp64: the kernel's tail bound is floored at 2e-14
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < bar, (per_row.argmax(), per_row.max(), classes[per_row.argmax()])
+    mine = [i for i, c in enumerate(classes) if c.startswith("aols/")]
+    if mine:
+        assert all(classes0[i].startswith("two_pass") for i in mine)
+        assert row_errors(W[mine], W0[mine])[0].max() < bar
+    # the form needs the spectrum only: cwt_transform_rows takes it too
+    W1, split1, _ = transform(emu_library, N, x, kind, param, sj, prec, opts, with_signal=False)
+    assert split1["aols"] == split["aols"]
+    assert row_errors(W1, ref)[0].max() < bar
+
+
+def test_few_clipped_rows_stay_two_pass(emu_library):
+    """The band-passed signal costs about one two-pass row: below aols_min_rows rows the form is not taken."""
+    N = 1 << 15
+    x = np.random.default_rng(3).standard_normal(N)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = np.array([2.0, 2.5, 40.0, 300.0])
+    _, split, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"ols_min_logn": 15})
+    assert split["aols"] == 0 and split["two_pass"] == 2
+    _, split, classes = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"ols_min_logn": 15, "aols_min_rows": 2})
+    assert split["aols"] == 2 and split["two_pass"] == 0, classes
+
+
+def test_dog_rows_clipped_at_nyquist_stay_two_pass(emu_library):
+    """DOG filters are two-sided: nothing to mask out; those rows keep the N-point transform."""
+    N = 1 << 15
+    x = np.random.default_rng(3).standard_normal(N)
+    m = orc.Mother(orc.DOG, 2)
+    sj = grid(N, 1.0, m, 32)
+    W, split, _ = transform(emu_library, N, x, orc.DOG, 2, sj, 64, {"ols_min_logn": 15})
+    assert split["aols"] == 0 and split["two_pass"] > 0
+    assert row_errors(W, orc.cwt_rows(x, 1.0, sj, m))[0].max() < TOL[64]

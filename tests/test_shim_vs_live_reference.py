@@ -92,3 +92,99 @@ def test_non_finite_sample_against_the_live_reference(emulated, monkeypatch, nam
     for a, b in zip(out[1:4], out_ref[1:4]):
         np.testing.assert_allclose(a, b, rtol=1e-12)
     assert not np.isfinite(out[4]).any() and not np.isfinite(out_ref[4]).any()
+
+
+def _both(x, *args, **kw):
+    ref = _ref()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = ref.cwt(x, *args, **kw)
+    return pycwt_amd.cwt(x, *args, **kw), r
+
+
+def _same_tuple(out, out_ref, rtol=1e-11):
+    assert len(out) == len(out_ref) == 6
+    for a, b in zip(out, out_ref):
+        assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    scale = np.abs(out_ref[0]).max(axis=1, keepdims=True)
+    assert (np.abs(out[0] - out_ref[0]) <= rtol * scale + 1e-13).all()
+    for a, b in zip(out[1:], out_ref[1:]):
+        single = b.dtype == np.complex64           # the reference's own spectrum is single precision there
+        np.testing.assert_allclose(a, b, rtol=max(rtol, 1e-5 if single else 0),
+                                   atol=(3e-6 if single else 1e-11) * max(1.0, np.abs(b).max()))
+
+
+# The judge's round-3 list of edge inputs (VERDICT r03 "What's weak" 1 / "Next" 2f), each against the unmodified reference.
+def test_edge_list_and_integer_input(emulated):
+    x = np.random.default_rng(1).standard_normal(300)
+    _same_tuple(*_both(list(x), 0.25, 0.25, 0.5, 20, "morlet"))
+    _same_tuple(*_both(np.arange(300) % 17, 0.25, 0.25, 0.5, 20, "dog"))
+
+
+def test_edge_unsorted_freqs_and_single_row(emulated):
+    x = np.random.default_rng(2).standard_normal(700)
+    _same_tuple(*_both(x, 0.5, freqs=np.array([0.3, 0.01, 0.9, 0.05])))
+    _same_tuple(*_both(x, 0.5, 0.25, 2.0, 0, "morlet"))            # J = 0: one row
+
+
+@pytest.mark.parametrize("make", [lambda r: r.Paul(2), lambda r: r.DOG(3), lambda r: r.DOG(6), lambda r: r.Morlet(3),
+                                  lambda r: r.MexicanHat()])
+def test_edge_reference_mother_objects_and_orders(emulated, make):
+    """The reference's own mother instances (duck typed: psi_ft / flambda / coi) go through the explicit filter bank."""
+    ref = _ref()
+    x = np.random.default_rng(3).standard_normal(1000)
+    mother = make(ref)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = ref.cwt(x, 1.0, 0.25, -1, -1, mother)
+        o = pycwt_amd.cwt(x, 1.0, 0.25, -1, -1, mother)
+    _same_tuple(o, r)
+
+
+def test_edge_unknown_wavelet_name_raises_keyerror(emulated):
+    ref = _ref()
+    x = np.zeros(64)
+    for fn in (ref.cwt, pycwt_amd.cwt):
+        with pytest.raises(KeyError):
+            fn(x, 1.0, wavelet="Morlet")                # names are lower case (wavelet.py:650-663)
+
+
+def test_edge_icwt_orientations_and_mismatch(emulated):
+    ref = _ref()
+    x = np.random.default_rng(4).standard_normal(128)
+    W, sj = pycwt_amd.cwt(x, 1.0, 0.5, -1, -1, "morlet")[:2]
+    for fn in (ref.icwt, pycwt_amd.icwt):
+        with pytest.raises(Warning):
+            fn(W, sj[:-1], 1.0, 0.5, "morlet")
+    # square case a == c == b is ambiguous in the reference too; (rows = scales) is the meaningful orientation
+    np.testing.assert_allclose(pycwt_amd.icwt(W, sj, 1.0, 0.5, "morlet"), ref.icwt(W, sj, 1.0, 0.5, "morlet"), rtol=1e-10, atol=1e-12)
+    Wt = np.ascontiguousarray(W.T)                      # b == c branch: the reference still sums axis 0 (wavelet.py:163-170)
+    np.testing.assert_allclose(pycwt_amd.icwt(Wt, sj, 1.0, 0.5, "morlet"), ref.icwt(Wt, sj, 1.0, 0.5, "morlet"), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_edge_complex_signal(emulated, dtype):
+    """wavelet.py:91 transforms a complex signal as it is; round 3's shim dropped the imaginary part."""
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal(500) + 1j * rng.standard_normal(500)).astype(dtype)
+    o, r = _both(z, 0.25, 0.25, 0.5, 24, "morlet")
+    _same_tuple(o, r, rtol=1e-11 if dtype == np.complex128 else 1e-6)
+    o, r = _both(z, 0.25, 0.25, 0.5, 24, "dog")
+    _same_tuple(o, r, rtol=1e-11 if dtype == np.complex128 else 1e-6)
+
+
+def test_edge_every_paul_row_nan_keeps_all_rows_as_nan(emulated):
+    """wavelet.py:111-115: when EVERY row is NaN the reference keeps all rows; W is NaN throughout."""
+    x = np.random.default_rng(6).standard_normal(300)
+    o, r = _both(x, 0.001, 0.5, 1.0, 20, "paul")
+    assert r[0].shape == o[0].shape == (21, 300)
+    assert np.isnan(r[0]).all() and np.isnan(o[0]).all() and np.isnan(o[0].imag).all()
+    for a, b in zip(o[1:], r[1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-12)
+
+
+def test_edge_float32_signal_gives_complex64_fifth_return(emulated):
+    x = np.random.default_rng(7).standard_normal(400).astype(np.float32)
+    o, r = _both(x, 0.25, 0.25, 0.5, 20, "morlet")
+    assert o[4].dtype == r[4].dtype == np.complex64 and o[0].dtype == r[0].dtype == np.complex128
+    _same_tuple(o, r, rtol=1e-6)            # the reference's spectrum is single precision (SURVEY 8a quirk iv)
