@@ -271,7 +271,8 @@ class Workload:
         }
         traffic_file, traffic_tab = None, {}
         tpath = os.path.join(ROOT, "profiles", f"traffic_{self.config}.json")
-        if os.path.exists(tpath) and not self.opts and N == 1 << 20 and self.rows_total == 256 and rt.shard == (0, 1):
+        default_opts = set(self.opts) <= {"tolerance"} and self.opts.get("tolerance") == BENCH_TOLERANCE[self.prec]
+        if os.path.exists(tpath) and default_opts and N == 1 << 20 and self.rows_total == 256 and rt.shard == (0, 1):
             traffic_file = f"profiles/traffic_{self.config}.json"
             traffic_tab = json.load(open(tpath))["per_kernel_class"]
         per_class = {}
@@ -427,13 +428,102 @@ class Workload:
             out = fn()
         el = time.perf_counter() - t0
         return {"value": len(sel) * float(self.N) / el / 1e9, "unit": "GSamples*scales/s", "cores": 1, "kind": kind,
-                "rows_returned": int(out[0].shape[0]),
+                "reference_mounted": kind == "reference", "rows_returned": int(out[0].shape[0]),
                 "sample": f"the whole cwt() (FFT, filter bank, batched inverse FFT, NaN scan, row copy) on {len(sel)} of "
                           f"the {len(self.sj_all)} rows at N={self.N}, once: {el:.1f} s"}
+
+    def icwt_pass(self, reps=10):
+        """BASELINE.md section 3 "icwt: report": the eq.-11 reduction (wavelet.py:169-170) over the device-resident W the
+        last step left, as a standalone pass (k_icwt reads every element of W once: 16 B / 8 B per sample*scale)."""
+        torch, rt = self.rt.torch, self.rt
+        out = torch.empty(self.N, dtype=torch.float64 if self.prec == 64 else torch.float32, device=rt.dev)
+        self.plan.icwt_reduce(self.W.data_ptr(), self.N, self.N, self.sj, 1.0, out.data_ptr())
+        rt.fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.plan.icwt_reduce(self.W.data_ptr(), self.N, self.N, self.sj, 1.0, out.data_ptr())
+        rt.fence()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        nbytes = float(len(self.sj)) * self.N * self.csize
+        return {"ms": ms, "algorithmic_bytes": nbytes, "achieved_GBs": nbytes / (ms * 1e-3) / 1e9,
+                "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm (read of W)",
+                "note": "standalone pass over W; fusing it into the row kernels was measured and rejected (EXPERIMENTS.md)"}
 
     def close(self):
         for lane in self.lanes:
             lane[0].close()
+
+
+def config1_latency(calls=300):
+    """BASELINE config 1: the reference's canonical call (sample/simple_sample.py:58-60: 504 points, dt = 0.25, dj = 1/12,
+    s0 = 0.5, J = 84, Morlet) through the drop-in pycwt_amd.cwt -- NumPy in, NumPy out, PCIe and launch latency included;
+    synthetic 504-point series (the NINO3 file is not on the GPU box; parity on the real data: tests/golden/nino3_*)."""
+    import pycwt_amd
+    from oracle import cwt_oracle as orc
+    x = np.random.default_rng(1234).standard_normal(504)
+    for _ in range(20):
+        pycwt_amd.cwt(x, 0.25, 1 / 12, 0.5, 84, "morlet")
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        out = pycwt_amd.cwt(x, 0.25, 1 / 12, 0.5, 84, "morlet")
+        ts.append(time.perf_counter() - t0)
+    ref = orc.cwt(x, 0.25, 1 / 12, 0.5, 84, orc.Mother(orc.MORLET, 6))
+    t0 = time.perf_counter()
+    for _ in range(20):
+        orc.cwt(x, 0.25, 1 / 12, 0.5, 84, orc.Mother(orc.MORLET, 6))
+    cpu_ms = (time.perf_counter() - t0) / 20 * 1e3
+    err = float((np.abs(out[0] - ref[0]).max(axis=1) / np.abs(ref[0]).max(axis=1)).max())
+    return {"workload": "pycwt_amd.cwt(x[504], 0.25, 1/12, 0.5, 84, 'morlet') -> 85 x 504 (BASELINE config 1)", "ms_per_call_median": float(np.median(ts) * 1e3),
+            "ms_per_call_min": float(np.min(ts) * 1e3), "oracle_ms_per_call_1_core": cpu_ms, "max_row_err": err, "calls": calls,
+            "includes": "host scale grid, H2D of the signal, kernels, D2H of W and the spectrum"}
+
+
+def config4_batch(rt, steps=3):
+    """BASELINE config 4 on ONE GPU at full size: 1024 signals x N = 2^16 x 128 Morlet scales through cwt_transform_batch,
+    W (137 GB complex128) device resident.  Roofline: 16 B per sample*scale over the timed step."""
+    from pycwt_amd import _hip
+    torch = rt.torch
+    nb, N, rows = 1024, 1 << 16, 128
+    sj = scale_grid(N, 1.0, flambda_of(0, 6.0), rows)
+    try:
+        g = torch.Generator(device=rt.dev)
+        g.manual_seed(1234)
+        X = torch.randn(nb, N, dtype=torch.float64, device=rt.dev, generator=g)
+        xh = torch.empty(nb, N, dtype=torch.complex128, device=rt.dev)
+        W = torch.empty(nb, rows, N, dtype=torch.complex128, device=rt.dev)
+    except RuntimeError as e:                       # not enough free memory on this device
+        return {"skipped": str(e)[:200]}
+    plan = _hip.Plan(N, 64, max_rows=nb * rows, device=rt.device_index, lib=rt.lib, options={"tolerance": BENCH_TOLERANCE[64]})
+    plan.set_stream(rt.stream_handle())
+
+    def step():
+        plan.transform_batch(X.data_ptr(), nb, N, N, 0, 6.0, 1.0, sj, xh.data_ptr(), W.data_ptr(), N, N)
+    step(); step(); rt.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    rt.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    split = plan.last_split()
+    # parity on a few (signal, scale) pairs against the oracle
+    from oracle import cwt_oracle as orc
+    m = orc.Mother(orc.MORLET, 6)
+    worst = 0.0
+    for b, j in ((0, 0), (511, 37), (1023, 127), (300, 90), (77, 5)):
+        ref = orc.cwt_rows(X[b].cpu().numpy(), 1.0, sj[j:j + 1], m)[0]
+        got = W[b, j].cpu().numpy()
+        worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
+    plan.close()
+    del X, xh, W
+    torch.cuda.empty_cache()
+    units = float(nb) * N * rows
+    return {"workload": "1024 signals x N=2^16 x 128 Morlet scales, one GPU, cwt_transform_batch (BASELINE config 4)",
+            "value": units / (ms * 1e-3) / 1e9, "unit": "GSamples*scales/s", "ms_per_step": ms, "steps": steps,
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": units * 16 + nb * N * 8.0,
+                         "frac_of_timed_step": (units * 16 + nb * N * 8.0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "row_split_per_call": split, "sampled_pairs_max_row_err": worst,
+            "parity_all_rows": "tests/test_gpu_parity.py::test_config4_full_batch_* (sampled pairs + Parseval on all 131072 rows)"}
 
 
 PRIME_MS = 80.0     # untimed device work before the W warm-up steps, see prime()
@@ -448,11 +538,14 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
         out = wl.timed(args.steps, args.warmup)
         out["from_idle"] = {"ms_per_step": idle["ms_per_step"], "value": idle["value"],
                             "note": "the same W warm-up + K timed steps started on an idle device (clocks still ramping)"}
+        out["effective_warmup_steps"] = args.warmup + primed_steps + args.warmup + args.steps    # everything that ran before
+        # the K timed steps of the headline: the from-idle pass (W + K), the priming steps, the W warm-up steps
         out["clock_priming"] = (f"{primed_steps} untimed steps (>= {PRIME_MS:.0f} ms of work) before the W warm-up steps: this "
                                 "GPU needs ~45 ms of work to go from its idle clock (sclk ~0.5 GHz) to its sustained clock "
                                 "(tools/clock_ramp.py, profiles/r03_clock_ramp.txt); the K timed steps are unchanged")
     else:
         out = wl.timed(args.steps, args.warmup)
+        out["effective_warmup_steps"] = args.warmup
     out["roofline"] = wl.roofline(args.steps)
     wp = out["roofline"].get("whole_path")
     if wp:
@@ -466,8 +559,11 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
     if want_cpu:
         wl.run_steps(1)
         rt.fence()
+        if not args.emulate:
+            out["icwt"] = wl.icwt_pass()
         out["cpu_baseline"], out["parity"] = wl.cpu_and_parity()
         out["cpu_baseline"]["reference_as_is"] = wl.reference_as_is()
+        out["cpu_baseline"]["reference_mounted"] = out["cpu_baseline"]["reference_as_is"]["reference_mounted"]
     out["dtype"] = "f64" if wl.prec == 64 else "f32"
     out["label"] = wl.label
     out["tolerance"] = wl.tolerance
@@ -503,6 +599,18 @@ def main():
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.shard:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU through torch.distributed.run on the
+        # loopback address, exactly what the driver's command line does; the ranks' one JSON line passes through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     # stdout carries exactly ONE line, the JSON result.  Libraries that write to the C stdout stream (RCCL prints
     # a version banner there on its first collective) are sent to stderr for the duration of the run.
@@ -553,8 +661,19 @@ def main():
         weak = measure(rt, args.config, args, args.rows * world, opts, want_cpu=False)
         out["weak_scaling"] = {"value": weak["value"], "ms_per_step": weak["ms_per_step"], "rows_total": args.rows * world,
                                "rows_per_gpu": args.rows}
+    for k in ("effective_warmup_steps", "icwt"):
+        if k in head:
+            out[k] = head[k]
     if single and args.config == "c2" and not args.no_extra and not opts and not args.emulate:
         out["extra"] = {}
+        # the same workload at the engine's own default accuracy (round-off: every truncation below fp64 rounding)
+        r = measure(rt, "c2", args, rows_total, {"tolerance": 1e-16}, want_cpu=False)
+        out["extra"]["c2_roundoff"] = {"workload": workload + ", tolerance 1e-16 (the engine's default)", "value": r["value"],
+                                       "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"], "tolerance": r["tolerance"],
+                                       "whole_path_frac": r["roofline"].get("whole_path_frac"),
+                                       "row_split": r["roofline"].get("row_split"), "from_idle": r.get("from_idle")}
+        out["extra"]["c1_nino3_latency"] = config1_latency()
+        out["extra"]["c4_batch"] = config4_batch(rt)
         for c in ("c3_paul", "c3_dog"):
             r = measure(rt, c, args, rows_total, {}, want_cpu=True)
             out["extra"][c] = {"workload": f"N=2^{args.logn} {r['label']} {rows_total} scales (BASELINE config 3)",

@@ -62,9 +62,17 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision /* 
 int cwt_plan_destroy(cwt_plan* plan);
 /* hipStream_t handle (as void*) all later launches of this plan are queued on. */
 int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
-/* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  Keys marked [lab] select measured-and-rejected kernel variants
- * or diagnostics that exist only in -DCWT_LAB builds of the library (tools/build_variants.py; DESIGN.md's experiment
- * tables); the product library refuses them.  Keys:
+/* Tuning / test hooks; unknown keys fail with CWT_EINVAL.  (The keys of the measured-and-rejected kernel variants and of the
+ * diagnostics of rounds 1-3 -- "overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched",
+ * "narrow_wave" -- are refused with a pointer to EXPERIMENTS.md: that code left the sources in round 4.)  Keys:
+ *   "poly"         0 = no band-limited rows in polynomial form (k_poly_*; default 1): they then run one K-point transform
+ *                  per output residue ("narrow*") or, where the call hands over the signal, as overlap-save rows
+ *   "poly_degree"  preferred largest degree of those rows (default 8): a row gets the smallest interval count K' (a power
+ *                  of two >= its support, >= 256, <= nfft / 64) whose degree does not exceed it
+ *   "poly_min_logn" log2 of the shortest transform that uses the form (default 16)
+ *   "aols"         0 = rows clipped at the Nyquist bins stay two-pass rows (default 1: overlap-save rows on the band-passed
+ *                  complex signal, k_aols_*; Morlet, Paul, and -- with the real signal at hand -- DOG of order >= 1)
+ *   "aols_min_rows" ... if at least this many rows qualify (default 3: the band-passed signal costs about one two-pass row)
  *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex); 0 = default:
  *                  as many rows as fit 192 MiB, so that the intermediate stays in the Infinity Cache
  *   "narrow"       0 disables the band-limited single-pass path
@@ -73,8 +81,6 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "wg_points"    complex points per workgroup of the fused kernels
  *   "narrow_terms" largest number of aliased bins per FFT input of that path at K = 1024 (1 = off, <= 16)
  *   "big_terms"    the same at K = 2048 (fp64, 16384-point workgroups; <= 8)
- *   "overlap"      [lab] 1 = run pass A of chunk c+1 beside pass B of chunk c on side
- *                  streams; 0 (default) = strictly one after the other
  *   "narrow_big"   0 = no K = 2048 single-pass rows (fp64, 16384-point workgroups)
  *   "overlap_narrow" 1 (default) = queue the band-limited rows on a side stream beside the two-pass chain
  *                  (+4 % in fp64; ignored while "profile" is on), 0 = everything on the plan's stream
@@ -87,8 +93,6 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  full-size instance is compiled for 64 VGPRs, which only its K = 1024 branches meet without spills:
  *                  0 is correct but slower)
  *   "two_pass_logk" log2 of the row length K of the two-pass split N = R*K (0 = default: 1024 up to 2^21, 2048 above)
- *   "pass_b_small" [lab] 1 = pass B on half-size workgroup tiles where the stores stay >= 128-byte segments (default 0)
- *   "stamps"       [lab] n > 0: record phase stamps of up to n workgroups (cwt_plan_read_stamps); 0 = off
  *   "big_tiles"    0 = complex128 pass A with 4096-point columns (N >= 2^23) on 8192-point tiles (default 1: 16384)
  *   "ols"          0 = no overlap-save rows in cwt_transform / cwt_execute_host (default 1)
  *   "ols_max_halo" largest halo H (samples, multiple of 64) of an overlap-save row; 0 = a quarter of the workgroup tile
@@ -96,14 +100,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  of two workgroup tiles; 2 = also blocks of FOUR tiles for halos in ["ols_big4_min_halo" (2048),
  *                  "ols_big4_max_halo" (8192)]: their block spectra are one 16384-point packed transform per block
  *                  (default: 1 for precision 32, 0 for 64; 2 measured -1 ... +3 % depending on the thresholds: the rows
- *                  gain what the extra block-spectra launch costs)
+ *                  gain what the extra block-spectra launch costs, EXPERIMENTS.md)
  *   "ols_small_max_halo" overlap-save rows with a halo up to this many samples (multiple of 64, default 512) run on
  *                  half-size workgroup tiles -- four block transforms in flight per CU instead of two; 0 = none
- *   "ols_fwd_real" [lab] 0 = block spectra of the overlap-save rows from a complex transform of the whole zero-imaginary block
- *                  instead of the half-length transform of the even/odd-packed block (default 1)
  *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
- *   "ols_tile"     [lab] points per workgroup of the overlap-save rows: 8192 (default), 1024 ... 4096 (tuning) or, precision 32
- *                  only, 16384
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
@@ -339,12 +339,6 @@ int cwt_shard_codes(const int* codes, int nrows, int precision, double nscale, i
 /* The model's estimate (microseconds per step) for a rank that owns exactly the rows with these codes. */
 int cwt_shard_cost(const int* codes, int nrows, int precision, double nscale, int chunk_rows, double* cost_us);
 
-/* Diagnostics (-DCWT_LAB builds; the product library never records): with option "stamps" = n (> 0) the two-pass kernels of the inverse transforms record, per workgroup,
- * 8 words: the 100 MHz wall clock at [0] start, [1] inputs arrived, [2] FFT done, [3] stores issued, [4] stores
- * acknowledged, [5] unused, [6] HW_ID | XCC_ID << 32, [7] blockIdx.x | blockIdx.y << 32 -- launch after launch in
- * issue order, until n records are used.  Copies up to cap_records records to out_host, returns the number recorded
- * since the last call in *n_records and starts over.  Synchronises the stream.                                       */
-int cwt_plan_read_stamps(cwt_plan* plan, uint64_t* out_host, int64_t cap_records, int64_t* n_records);
 /* How the last cwt_transform_rows / cwt_transform call split its rows: counts[0] = rows done by the single-workgroup
  * kernel, [1] = band-limited single pass with K <= 1024 and at most 4 aliased terms, [2] = two-pass, [3] = band-limited
  * single pass with K = 2048 (fp64, 16384-point workgroups), [4] = band-limited single pass with K = 1024 and 5..16

@@ -68,7 +68,6 @@ SYMBOLS = [
     ("cwt_plan_row_classes", C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     ("cwt_plan_classify", C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int64,
                                     C.c_int, C.POINTER(C.c_int)]),
-    ("cwt_plan_read_stamps", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("cwt_plan_last_split", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("cwt_plan_last_split8", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("cwt_plan_balanced_shards", C.c_int, [_P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int64,
@@ -451,14 +450,6 @@ class Plan:
             else:
                 out.append(f"narrow/K{1 << logk}" + (f"/t{terms}" if terms > 1 else ""))
         return out
-
-    @_locked
-    def read_stamps(self, cap: int):
-        """(n_recorded, records[min(n, cap), 8] uint64) of the phase stamps since the last call (option "stamps")."""
-        out = np.zeros((cap, 8), dtype=np.uint64)
-        n = C.c_int64(0)
-        self.lib.check(self.lib.cwt_plan_read_stamps(self.h, out.ctypes.data_as(_P), cap, C.byref(n)))
-        return n.value, out[:min(n.value, cap)]
 
     @_locked
     def last_split(self):

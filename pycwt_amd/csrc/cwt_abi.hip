@@ -181,16 +181,12 @@ struct cwt_plan {
   int narrow_small = 1;    // complex64: K <= 512 band-limited rows on half-size tiles
   int narrow_mix = 0;      // launch order of the band-limited rows alternates light and heavy rows (default: on for
                            // precision 64 -- measured -3.5 % on that kernel, -2 % on the step; +-0 / -2 % in fp32)
-  int narrow_wave = 0;     // [lab] band-limited rows with K <= 128 on the barrier-free kernel (one transform per wavefront)
   int big_tiles = 1;       // complex128, R = 4096: pass A on 16384-point tiles
   int force_logk = 0;
   int narrow_big = 1;      // fp64: K = 2048 single-pass rows on 16384-point workgroups
   int overlap_narrow = 1;  // band-limited rows on a side stream beside the two-pass chain (measured: +4 % in
                            // fp64); ignored while "profile" is on so that every timed kernel runs alone
   int band_pass_a = 1;     // pass A with short aliased column FFTs for rows of moderate support
-  int overlap = 0;         // run pass A of chunk c+1 beside pass B of chunk c on side streams
-  int pass_b_prefetch = 0; // pass B as a 2- or 4-tile walk per workgroup with the next tile's loads in flight
-  int pass_b_small = 0;    // pass B on half-size workgroup tiles when that keeps TB >= 8 (K <= wg_points / 16)
   int ols = 1;             // overlap-save rows (time-compact wavelets) when the call hands over the signal itself
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
@@ -202,8 +198,6 @@ struct cwt_plan {
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
-  int ols_tile = 8192;     // points per workgroup of those rows (fp32: 8192 or 16384)
-  int ols_fwd_real = 1;    // block spectra from a complex transform of half the block length (real-input packing)
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
   int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
@@ -218,9 +212,6 @@ struct cwt_plan {
                               // dynamic range of the call's spectrum (cwt_plan_set_auto_tolerance)
   double last_range = 0.0;    // max|xhat| / rms|xhat| of the last such call
   double* range_dev = nullptr;
-  // phase stamps (diagnostics): 8 words per workgroup of the stamped two-pass launches
-  unsigned long long* stamps = nullptr;
-  int64_t stamp_cap = 0, stamp_next = 0;
   // device resources
   void* tw_all = nullptr;   // e^{2 pi i p / L} for L = 2,4,..,16384; table of L starts at L-2
   void* twn_lo = nullptr;   // e^{2 pi i i / N}, i < 2^twn_shift
@@ -305,9 +296,7 @@ struct cwt_plan {
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
   hipEvent_t ev_ols = nullptr;
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
-  hipStream_t side_hi = nullptr;     // the same at the highest priority (option "sched" bit 1)
   hipEvent_t ev_big = nullptr;
-  int sched = 0;                     // stream placement experiments (bit 0: join side2 directly; bit 1: few-row kernels at high priority)
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
@@ -665,18 +654,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   const bool big_ok = p->use_ct && p->narrow_big && p->prec == 64 && narrow_cap >= 10 && logP == 13 &&
                       p->logN >= 14;
   // overlap-save rows: default geometry, at least 4 workgroup tiles per row, built-in mothers, one shared spectrum
-  // workgroup tile of the overlap-save rows: 8192 points (512 threads); fp32 may also use 16384 (option "ols_tile")
-  const int ols_logp = (p->prec == 32 && p->ols_tile == 16384) ? 14 : p->ols_tile == 4096 ? 12 : p->ols_tile == 2048 ? 11 : p->ols_tile == 1024 ? 10 : 13;
+  // workgroup tile of the overlap-save rows: 8192 points (512 threads)
+  const int ols_logp = 13;
   // half-size tiles for short halos (only beside the default 8192-point tile)
   const int ols_logp_s = (p->ols_small_max_halo > 0 && ols_logp == 13) ? 12 : 0;
   // a batch of signals (cwt_transform_batch: rows_per_signal > 0 with the signals at hand) has nbatch times the blocks
   // of one signal to fill the GPU with, so the form pays from shorter transforms: the threshold counts the batch
   const int ols_nbatch = (rows_per_signal > 0 && ols_ncols > 0) ? std::max(1, nrows / rows_per_signal) : 1;
-#ifdef CWT_LAB
-  const bool ols_batch_ok = p->ols_fwd_real != 0;      // the lab's complex block transform has no batch form
-#else
   const bool ols_batch_ok = true;
-#endif
   const bool ols_layout = rows_per_signal > 0 ? (ols_batch_ok && ols_ncols > 0 && nrows % rows_per_signal == 0) : spec_ld == 0;
   const bool ols_ok = p->ols && ols_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) &&
                       p->logN + ilog2(ols_nbatch) >= p->ols_min_logn && p->logN >= ols_logp + 2 &&
@@ -690,9 +675,11 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // gives the sampled wavelet its slow 1/t tail; measured error of the form ~ a tenth of that fraction)
   // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*): needs the spectrum only;
   // Morlet and Paul (a real mother constant and nothing to keep on the masked-out bins), one shared spectrum
+  // DOG (order >= 1): also, but only when the call hands over the REAL signal (its negative bins are the mirror image then)
   const bool aols_ok = p->ols && p->aols && out_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) &&
-                       p->logN >= p->ols_min_logn && (mother == MOTHER_MORLET || mother == MOTHER_PAUL) &&
-                       rows_per_signal == 0 && spec_ld == 0 && !use_small;
+                       p->logN >= p->ols_min_logn && rows_per_signal == 0 && spec_ld == 0 && !use_small &&
+                       (mother == MOTHER_MORLET || mother == MOTHER_PAUL ||
+                        (mother == MOTHER_DOG && param >= 1 && ols_ncols > 0));
   double fc_lo = 0, fc_hi = 0;
   if (ols_ok || aols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows, poly_rows;
@@ -711,6 +698,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     rd.aux_off = 0;
+    rd.nyq_re = rd.nyq_im = 0.0;
     double row_lo = f_lo, row_hi = f_hi, row_best = 0.0;     // row_best: log of the filter's largest value on the row's bins / its peak
     if (mother != MOTHER_TABLE) {
       // The support threshold is meant relative to the largest value the filter takes ON THE ROW'S BINS.  Where the bins
@@ -854,7 +842,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         const int cls = span <= 16 ? 4 : span <= 64 ? 6 : span <= 256 ? 8 : 0;
         rd.logK = (band_pass_a && cls && cls < two_pass_logr) ? cls : 0;   // only if shorter than the column
         wide_rows.push_back(rd);
-        wide_clipped.push_back(aols_ok && !vanishes && rd.nband > 0 && amp_im[j] == 0.0);
+        wide_clipped.push_back(aols_ok && !vanishes && rd.nband > 0 &&
+                               (mother == MOTHER_DOG ? (amp_re[j] == 0.0) != (amp_im[j] == 0.0) : amp_im[j] == 0.0));
       }
     }
   }
@@ -880,6 +869,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         if (0.5 + ag.f_s < 0.12) ag.f_s = ag.f1_lo - 1.0 / 128.0;
         geom_ok = 0.5 + ag.f_s >= 0.10;                   // room for the taper above Nyquist
         aols_ks = int(std::ceil(ag.f_s * double(N)));
+      } else if (mother == MOTHER_DOG) {
+        // two-sided profile, smooth through f = 0: the mask is the positive bins 1 .. N/2 - 1 (the negative ones are their
+        // mirror image, added by the kernel's epilogue), the window continues the profile below 0 and tapers it there
+        // (a quarter cycle each side: the profile is NOT small there, so the tapers must be as gentle as the one above Nyquist)
+        ag.f1_lo = 0.0;
+        ag.f_s = -0.25;
+        aols_ks = 1;
       } else {                                             // Paul: Heaviside -- the mask starts at bin 1
         ag.f1_lo = ag.f_s = 1.0 / double(N);
         aols_ks = 1;
@@ -912,6 +908,16 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         o.amp_im = 0.0;
         o.k_lo = ag.ksp; o.nband = P;
         o.logK = aols_logp; o.nterms = 1;
+        o.nyq_re = o.nyq_im = 0.0;
+        if (mother == MOTHER_DOG) {
+          const int mm = int(std::lround(param));
+          const bool odd = (mm & 1) != 0;
+          o.nterms = odd ? 3 : 2;                           // W = 2 Re y | -2 Im y (table scale = the non-zero part of amp)
+          if (odd) o.amp_re = amp_im[o.out_row] / double(P);
+          const double pn = host_profile(mother, param, wide_rows[i].a * double(N / 2)) * (odd ? -1.0 : 1.0) / double(N);
+          o.nyq_re = amp_re[o.out_row] * pn;                // F_j at the Nyquist bin (w = -pi / dt, wavelet.py:94) / N
+          o.nyq_im = amp_im[o.out_row] * pn;
+        }
         o.spec_off = 0;
         o.tab_off = toff;
         toff += P;
@@ -1082,7 +1088,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     p->rt->aols_geom = ag;
     p->rt->aols_wgs = long((ag.nblocks + 7) / 8) * 8 * ag.nrows;
     p->rt->aols_gt_elems = long(aols_rows.size()) << aols_logp;
-    RowDesc m{};                                          // the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)
+    RowDesc m{};                                          // (zero-initialised: no Nyquist term) the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)
     m.a = 0.0; m.amp_re = 1.0 / double(N); m.amp_im = 0.0;
     m.k_lo = aols_ks; m.nband = int(N / 2) - aols_ks;
     m.out_row = 0; m.logK = 0; m.nterms = 1; m.spec_off = 0; m.tab_off = 0;
@@ -1236,24 +1242,10 @@ void launch_narrow_ct_all(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cp
   int n_small_k, n_big;
   narrow_class_counts(p, &n_small_k, &n_big);
   int n_wave = 0;
-#ifdef CWT_LAB
-  // rows with K <= 128 and one term (sorted first) on the barrier-free kernel, one transform per wavefront (measured slower)
-  if (p->narrow_wave && p->logN >= LOGP)
-    for (const auto& g : p->rt->narrow_groups) if (g.logK <= 7 && g.nterms == 1) n_wave += g.count;
-  for (int r0 = 0; r0 < n_wave; r0 += kMaxGridY)
-    hipLaunchKernelGGL((k_narrow_wave<T, LOGP>), dim3(1u << (p->logN - LOGP), std::min(kMaxGridY, n_wave - r0)),
-                       dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), p->stream, xhat,
-                       p->rt->rows_dev + first + r0, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
-                       p->logN, W, long(ldw), long(ncols));
-#endif
   // complex64 only: rows with K <= 512 (sorted first) on half-size workgroup tiles (store segments stay
   // >= 128 B): -6 % on this kernel; complex128 measured +7 %
   int n_half = 0;
-#ifdef CWT_LAB
-  constexpr bool kHalfTiles64 = true;            // p->narrow_small == 2: fp64 too (measured +7 %)
-#else
   constexpr bool kHalfTiles64 = false;
-#endif
   if constexpr (sizeof(T) == 4 || kHalfTiles64) {
     if (p->narrow_small && (sizeof(T) == 4 || p->narrow_small == 2) && p->logN >= LOGP)
       for (const auto& g : p->rt->narrow_groups) if (g.logK <= 9 && g.nterms == 1) n_half += g.count;
@@ -1315,41 +1307,17 @@ void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt,
                      tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
 }
 
-// Stamp records of one launch of `blocks` workgroups (base == nullptr: none left or stamping is off).
-Stamps take_stamps(cwt_plan* p, int64_t blocks) {
-  Stamps st{nullptr, 0u};
-  if (p->stamps && p->stamp_next + blocks <= p->stamp_cap) {
-    st.base = p->stamps;
-    st.first = unsigned(p->stamp_next);
-    p->stamp_next += blocks;
-  }
-  return st;
-}
-
 template <typename T, int LOGR, int LP>
 void launch_pass_a_ct_rows_lp(cwt_plan* p, const void* in, const RowDesc* rows, int cnt, const Mother& mo,
                               cplx<T>* Z, hipStream_t st) {
   const dim3 grid(1u << (p->logN - LP), cnt), block(1 << (LP - 4));
   const size_t lds = (size_t(1) << LP) * sizeof(T);
-  const Stamps sp = take_stamps(p, int64_t(grid.x) * grid.y);
   if constexpr (LP == 14) {
-#ifdef CWT_LAB
-    static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, false>),
-                              allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, true>), true);
-#else
-    static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP, false>), true);
-#endif
+    static const bool once = (allow_big_lds(&k_pass_a_ct_rows<T, LOGR, LP>), true);
     (void)once;
   }
-#ifdef CWT_LAB
-  if (sp.base) {
-    hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, true>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
-                       rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
-    return;
-  }
-#endif
-  hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP, false>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
-                       rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z, sp);
+  hipLaunchKernelGGL((k_pass_a_ct_rows<T, LOGR, LP>), grid, block, lds, st, static_cast<const cplx<T>*>(in),
+                       rows, mo, static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), p->logN, Z);
 }
 
 template <typename T, int LOGR>
@@ -1387,43 +1355,14 @@ void launch_pass_b_ct_lp(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, 
                          const cplx<T>* Z, hipStream_t st) {
   const size_t lds = ((size_t(1) << LP) + (size_t(1) << (LP - 4))) * sizeof(T);
   const dim3 grid(1u << (p->logN - LP), cnt), block(1 << (LP - 4));
-  const Stamps sp = CONJ ? Stamps{nullptr, 0u} : take_stamps(p, int64_t(grid.x) * grid.y);
-#ifdef CWT_LAB
-  if constexpr (!CONJ) {
-    if (sp.base) {
-      hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, true>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
-                         twn_of<T>(p), p->logN, W, long(ldw), long(ncols), sp);
-      return;
-    }
-  }
-#endif
-  hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ, false>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
-                     twn_of<T>(p), p->logN, W, long(ldw), long(ncols), sp);
+  hipLaunchKernelGGL((k_pass_b_ct<T, LOGK, LP, CONJ>), grid, block, lds, st, Z, rows, tw_table<T>(p, LOGK),
+                     twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
 }
 
 template <typename T, int LOGK, bool CONJ>
 void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
                       const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
-#ifdef CWT_LAB
-  if constexpr (!CONJ && LOGK == 10) {
-    const unsigned ntiles = 1u << (p->logN - LOGP);
-    if (p->pass_b_prefetch && !p->stamps && ntiles >= 32) {
-      const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-      if (p->pass_b_prefetch == 4)
-        hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 4>), dim3(ntiles / 4, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
-                           rows, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
-      else
-        hipLaunchKernelGGL((k_pass_b_ct_pf<T, LOGK, LOGP, 2>), dim3(ntiles / 2, cnt), dim3(1 << (LOGP - 4)), lds, st, Z,
-                           rows, tw_table<T>(p, LOGK), twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
-      return;
-    }
-  }
-  // half-size tiles keep the store segments >= 128 B only while TB = 2^(LOGP - 1 - LOGK) >= 128 B / sizeof(complex)
-  if constexpr (!CONJ && LOGP - 1 - LOGK >= (sizeof(T) == 8 ? 3 : 4)) {
-    if (p->pass_b_small) return launch_pass_b_ct_lp<T, LOGK, LOGP - 1, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
-  }
-#endif
   launch_pass_b_ct_lp<T, LOGK, LOGP, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
 }
 
@@ -1500,20 +1439,6 @@ int fft_rows_impl(cwt_plan* p, const void* in_dev, int64_t in_ld, int nrows, int
   return CWT_OK;
 }
 
-#ifdef CWT_LAB
-// Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd) ...
-template <typename T, int LOGM, int LOGD>
-int launch_ols_fwd_b(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, const OlsClasses& cls, hipStream_t st) {
-  static const bool once = (allow_big_lds(&k_ols_fwd<T, LOGM, LOGD>), true);
-  (void)once;
-  const size_t lds = ((size_t(1) << LOGM) + (size_t(1) << (LOGM - 4))) * sizeof(T);
-  return timed_launch(p, KC_OLS_FWD, [&] {
-    hipLaunchKernelGGL((k_ols_fwd<T, LOGM, LOGD>), dim3(unsigned(blocks << LOGD)), dim3(1 << (LOGM - 4)), lds, st,
-                       static_cast<const T*>(x_dev), long(n0), p->logN, cls,
-                       static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p), static_cast<cplx<T>*>(p->xs));
-  }, st);
-}
-#endif
 // Overlap-save rows of the current row table: block spectra of the real signal x_dev (k_ols_fwd_r; block length
 // 2^(LOGM + 1)) ...
 template <typename T, int LOGM>
@@ -1531,9 +1456,6 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
 template <typename T>
 int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
   int rc = CWT_OK;
-#ifdef CWT_LAB
-  if (p->ols_fwd_real)
-#endif
   {
     for (int g = 0; g < 2 && !rc; ++g) {
       const auto& G = p->rt->ols_grp[g];
@@ -1541,10 +1463,6 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
       for (int d = 0; d < 3 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
-#ifdef CWT_LAB
-          case 10: rc = launch_ols_fwd_r<T, 9>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
-          case 11: rc = launch_ols_fwd_r<T, 10>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
-#endif
           case 12: rc = launch_ols_fwd_r<T, 11>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 13: rc = launch_ols_fwd_r<T, 12>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 14: rc = launch_ols_fwd_r<T, 13>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
@@ -1555,27 +1473,6 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
     }
     return rc;
   }
-#ifdef CWT_LAB
-  for (int g = 0; g < 2 && !rc; ++g) {
-    const auto& G = p->rt->ols_grp[g];
-    const long* nb = G.fwd_blocks;
-    if (!G.nrows) continue;
-    switch (G.logp) {
-      case 10: if (nb[0]) rc = launch_ols_fwd_b<T, 10, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
-      case 11: if (nb[0]) rc = launch_ols_fwd_b<T, 11, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
-      case 12: if (nb[0]) rc = launch_ols_fwd_b<T, 12, 0>(p, x_dev, n0, nb[0], G.cls, st); break;
-      case 13:
-        if (nb[0]) rc = launch_ols_fwd_b<T, 13, 0>(p, x_dev, n0, nb[0], G.cls, st);
-        if (!rc && nb[1]) rc = launch_ols_fwd_b<T, 13, 1>(p, x_dev, n0, nb[1], G.cls, st);   // double-length blocks, two tiles each
-        break;
-      case 14:
-        if constexpr (sizeof(T) == 4) { if (nb[0]) rc = launch_ols_fwd_b<T, 14, 0>(p, x_dev, n0, nb[0], G.cls, st); }
-        break;
-      default: return fail(CWT_EINVAL, "overlap-save tile size");
-    }
-  }
-  return rc;
-#endif
 }
 // ... and the rows themselves (k_ols_ct)
 template <typename T, int LOGP>
@@ -1599,11 +1496,6 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows) continue;
     switch (G.logp) {
-#ifdef CWT_LAB
-      case 10: rc = launch_ols_rows_p<T, 10>(p, g, W, ldw, ncols, st); break;
-      case 11: rc = launch_ols_rows_p<T, 11>(p, g, W, ldw, ncols, st); break;
-      case 14: if constexpr (sizeof(T) == 4) rc = launch_ols_rows_p<T, 14>(p, g, W, ldw, ncols, st); break;
-#endif
       case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
       case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
       default: return fail(CWT_EINVAL, "overlap-save tile size");
@@ -1649,7 +1541,8 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   return timed_launch(p, KC_AOLS, [&] {
     hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs)), dim3(1 << (LOGP - 4)), lds, st,
                        static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first,
-                       static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g, W, long(ldw), long(ncols));
+                       static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
+                       static_cast<const cplx<T>*>(xhat_dev) + (p->N >> 1), W, long(ldw), long(ncols));
   }, st);
 }
 template <typename T>
@@ -1756,11 +1649,11 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   if (p->rt->n_ols && !x_dev) return fail(CWT_EINVAL, "overlap-save rows need the signal");
   // (short transforms run their kernels back to back: at N = 2^16 / 2^17 the events and waits of the side streams cost
   // more than the overlap returns -- measured 0.149 against 0.129 ms and 0.226 against 0.204 ms per 256-row transform)
-  const bool side_narrow = p->overlap_narrow && !p->profile && !p->overlap && (p->rt->n_wide || p->rt->n_ols || p->rt->n_aols) &&
+  const bool side_narrow = p->overlap_narrow && !p->profile && (p->rt->n_wide || p->rt->n_ols || p->rt->n_aols) &&
                            (p->rt->n_narrow || p->rt->n_poly) && logN >= 18;
   // block spectra of the overlap-save rows: beside the two-pass chain on side stream 1 (they only need the signal)
   const bool ols_early = p->rt->n_ols && p->ols_launched;       // already queued on side stream 1 by cwt_transform
-  const bool ols_side = p->rt->n_ols && !ols_early && p->ols_side && !p->profile && !p->overlap && p->rt->n_wide;
+  const bool ols_side = p->rt->n_ols && !ols_early && p->ols_side && !p->profile && p->rt->n_wide;
   if (p->rt->n_ols && !ols_early) {
     rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
     if (rc) return rc;
@@ -1773,44 +1666,29 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
-  if (p->rt->n_wide) {
+  if (p->rt->n_wide) {                 // two-pass rows, chunk by chunk on the plan's stream (one intermediate buffer)
     const int logK = two_pass_logk(p), logR = logN - logK;
     const int chunk = balanced_chunk(p, p->rt->n_wide);
     const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
-    const bool pipelined = p->overlap && nchunks > 1;
-    rc = ensure_z(p, pipelined ? 2 * chunk : chunk);
+    rc = ensure_z(p, chunk);
     if (rc) return rc;
-    // Pipelined: pass A of chunk c+1 (latency/VALU bound) runs on side stream 0 beside pass B of
-    // chunk c (memory bound) on side stream 1, through two intermediate buffers.
-    hipStream_t sa = pipelined ? p->side[0] : p->stream, sb = pipelined ? p->side[1] : p->stream;
-    if (pipelined) {
-      HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
-      HIPCHECK(hipStreamWaitEvent(sa, p->ev_fork, 0));
-      HIPCHECK(hipStreamWaitEvent(sb, p->ev_fork, 0));
-    }
+    cplx<T>* Z = static_cast<cplx<T>*>(p->Z);
     for (int c = 0; c < nchunks; ++c) {
-      const int first = c * chunk, cnt = std::min(chunk, p->rt->n_wide - first), buf = pipelined ? (c & 1) : 0;
+      const int first = c * chunk, cnt = std::min(chunk, p->rt->n_wide - first);
       const RowDesc* rows = p->rt->rows_dev + p->rt->wide_first + first;
-      cplx<T>* Z = static_cast<cplx<T>*>(p->Z) + size_t(buf) * size_t(chunk) * size_t(p->N);
-      if (pipelined && c >= 2) HIPCHECK(hipStreamWaitEvent(sa, p->ev_b[buf], 0));   // buffer is free again
       rc = timed_launch(p, KC_PASS_A, [&] {
-        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, 0L, Z, sa)) return;
-        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sa,
+        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, 0L, Z, p->stream)) return;
+        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
                            xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, 0L, Z);
-      }, sa);
+      });
       if (rc) return rc;
-      if (pipelined) {
-        HIPCHECK(hipEventRecord(p->ev_a[buf], sa));
-        HIPCHECK(hipStreamWaitEvent(sb, p->ev_a[buf], 0));
-      }
       rc = timed_launch(p, KC_PASS_B, [&] {
-        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, sb)) return;
-        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, sb,
+        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, p->stream)) return;
+        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
                            static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), twn_of<T>(p), logN, logK,
                            logP - logK, W, long(ldw), long(ncols));
-      }, sb);
+      });
       if (rc) return rc;
-      if (pipelined) HIPCHECK(hipEventRecord(p->ev_b[buf], sb));
     }
   }
   if (p->rt->n_aols) {                 // after the two-pass chain: both use the intermediate buffer
@@ -1820,14 +1698,6 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   if (ols_early) {
     HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
   } else if (p->rt->n_ols) {
-    if (p->overlap && p->rt->n_wide) {   // the pipelined two-pass chain lives on the side streams: join it first
-      const int chunk = balanced_chunk(p, p->rt->n_wide);
-      const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
-      if (nchunks > 1) {
-        HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
-        HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
-      }
-    }
     if (ols_side) HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_ols, 0));
     else rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream);
     if (!rc) rc = launch_ols_rows<T>(p, W, ldw, ncols, p->stream);
@@ -1855,7 +1725,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
       // the multi-term kernels (few rows, long workgroups) on a stream of their own: at small row counts (a rank's
       // share of 8) they would otherwise run alone at the end of the step
       const bool big_on_side2 = narrow_on_side && n_small_k && (n_many || n_big);
-      hipStream_t sbig = (p->sched & 2) ? p->side_hi : p->side2;
+      hipStream_t sbig = p->side2;
       if (big_on_side2) {
         HIPCHECK(hipStreamWaitEvent(sbig, p->ev_fork, 0));
         p->stream = sbig;
@@ -1866,8 +1736,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
       if (rc) return rc;
       if (big_on_side2) {
         HIPCHECK(hipEventRecord(p->ev_big, sbig));
-        if (p->sched & 1) HIPCHECK(hipStreamWaitEvent(keep, p->ev_big, 0));   // joined directly
-        else HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_big, 0));          // joined through side stream 0
+        HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_big, 0));          // joined through side stream 0
       }
       if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
     } else {
@@ -1881,14 +1750,6 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
         });
         if (rc) return rc;
       }
-    }
-  }
-  if (p->rt->n_wide) {
-    const int chunk = balanced_chunk(p, p->rt->n_wide);
-    const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
-    if (p->overlap && nchunks > 1) {   // join: every pass A is followed by its pass B on side stream 1
-      HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 1) & 1], 0));
-      HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_b[(nchunks - 2) & 1], 0));
     }
   }
   if (narrow_on_side) HIPCHECK(hipStreamWaitEvent(p->stream, p->ev_a[0], 0));
@@ -2028,14 +1889,6 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
-#ifdef CWT_LAB
-  if (!rc) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&p->side_hi, hipStreamNonBlocking, greatest) != hipSuccess)
-      rc = fail(CWT_EHIP, "cannot create side streams/events");
-  }
-#endif
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
@@ -2070,11 +1923,10 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
-  if (p->side_hi) { (void)hipStreamSynchronize(p->side_hi); (void)hipStreamDestroy(p->side_hi); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
-  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->range_dev, p->hx, p->hxhat, p->hW, p->stamps,
+  void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->range_dev, p->hx, p->hxhat, p->hW,
                   p->bs_khat[0], p->bs_khat[1], p->bs_a, p->bs_spec, p->bs_par};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (auto& t : p->slots) {
@@ -2103,13 +1955,10 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   if (!p || !key) return fail(CWT_EINVAL, "plan/key is NULL");
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
-#ifndef CWT_LAB
-  for (const char* lab : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched",
-                          "narrow_wave"})
-    if (k == lab)
-      return fail(CWT_EINVAL, "option " + k + " exists only in -DCWT_LAB builds of the library (tools/build_variants.py): "
-                              "a measured-and-rejected variant or a diagnostic");
-#endif
+  for (const char* gone : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched", "narrow_wave"})
+    if (k == gone)
+      return fail(CWT_EINVAL, "option " + k + " belonged to a measured-and-rejected variant or a diagnostic that left the sources in "
+                              "round 4 (EXPERIMENTS.md names the commit that still has it)");
   for (auto& t : p->slots) t.key.clear();   // the classification depends on the options
   struct Restore {   // a rejected geometry leaves every geometry-affecting field as it was
     cwt_plan* p; int lmax, wg, logk, nmax;
@@ -2124,37 +1973,15 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "wg_points") { if (!pow2(value) || value < 256 || value > 16384) return fail(CWT_EINVAL, "wg_points: power of two in [256,16384]"); p->log_wg_points = ilog2(value); }
   else if (k == "profile") p->profile = value != 0;
   else if (k == "ct") p->use_ct = value != 0;
-  else if (k == "overlap") p->overlap = value != 0;
   else if (k == "band_pass_a") p->band_pass_a = value != 0;
   else if (k == "overlap_narrow") p->overlap_narrow = value != 0;
   else if (k == "narrow_big") p->narrow_big = value != 0;
   else if (k == "narrow_mix") p->narrow_mix = value != 0;
-  else if (k == "narrow_wave") p->narrow_wave = value != 0;
   else if (k == "two_pass_logk") { if (value < 0 || value > 12) return fail(CWT_EINVAL, "two_pass_logk in [0,12] (0 = default)"); p->force_logk = int(value); }
   else if (k == "big_tiles") p->big_tiles = value != 0;
-#ifdef CWT_LAB
-  else if (k == "narrow_small") p->narrow_small = int(value);      // 2: complex128 rows too
-#else
   else if (k == "narrow_small") p->narrow_small = value != 0;
-#endif
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
-  else if (k == "pass_b_small") p->pass_b_small = value != 0;
-  else if (k == "pass_b_prefetch") { if (value != 0 && value != 2 && value != 4) return fail(CWT_EINVAL, "pass_b_prefetch: 0, 2 or 4 tiles"); p->pass_b_prefetch = int(value); }
-  else if (k == "stamps") {
-    if (value < 0 || value > (int64_t(1) << 24)) return fail(CWT_EINVAL, "stamps: record count in [0, 2^24]");
-    HIPCHECK(hipSetDevice(p->device));
-    HIPCHECK(hipStreamSynchronize(p->stream));
-    if (p->stamps) { HIPCHECK(hipFree(p->stamps)); p->stamps = nullptr; }
-    p->stamp_cap = p->stamp_next = 0;
-    if (value > 0) {
-      if (hipMalloc(reinterpret_cast<void**>(&p->stamps), size_t(value) * 64) != hipSuccess)
-        return fail(CWT_ENOMEM, "stamp buffer allocation failed");
-      HIPCHECK(hipMemset(p->stamps, 0, size_t(value) * 64));
-      p->stamp_cap = value;
-    }
-  }
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
-  else if (k == "sched") p->sched = int(value);
   else if (k == "ols") p->ols = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
@@ -2166,8 +1993,6 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_big4_max_halo") { if (value < 2048 || value > 8192 || (value & 63)) return fail(CWT_EINVAL, "ols_big4_max_halo: multiple of 64 in [2048, 8192]"); p->ols_big4_max_halo = int(value); }
   else if (k == "ols_big4_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big4_min_halo in [64, 8192]"); p->ols_big4_min_halo = int(value); }
   else if (k == "ols_min_logn") { if (value < 15 || value > 24) return fail(CWT_EINVAL, "ols_min_logn in [15, 24]"); p->ols_min_logn = int(value); }
-  else if (k == "ols_tile") { if (value != 8192 && value != 4096 && value != 2048 && value != 1024 && !(value == 16384 && p->prec == 32)) return fail(CWT_EINVAL, "ols_tile: 1024, 2048, 4096, 8192 (or 16384 with precision 32)"); p->ols_tile = int(value); }
-  else if (k == "ols_fwd_real") p->ols_fwd_real = value != 0;
   else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
@@ -2353,7 +2178,8 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   const RowDesc* rows = t->rows_dev + t->aols_first;
   T* gt = static_cast<T*>(t->agt_dev);
   if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
-  else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
+  else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
+  else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
   HIPCHECK(hipGetLastError());
   return CWT_OK;
 }
@@ -2446,7 +2272,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   }
   const Mother mo = mother_of(mother, param);
   p->ols_launched = 0;
-  if (p->rt->n_ols && p->ols_early && !p->profile && !p->overlap) {
+  if (p->rt->n_ols && p->ols_early && !p->profile) {
     rc = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
                        : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
     if (rc) return rc;
@@ -3116,17 +2942,6 @@ int cwt_plan_balanced_shards(cwt_plan* p, int mother, double param, double dt, c
   int rc = cwt_plan_classify(p, mother, param, dt, scales, nrows, ncols, 1, codes.data());
   if (rc) return rc;
   return cwt_shard_codes(codes.data(), nrows, p->prec, double(p->N) / double(1 << 20), chunk_rows_of(p), world, first, count);
-}
-
-int cwt_plan_read_stamps(cwt_plan* p, uint64_t* out_host, int64_t cap_records, int64_t* n_records) {
-  if (!p || !n_records) return fail(CWT_EINVAL, "NULL argument");
-  HIPCHECK(hipSetDevice(p->device));
-  HIPCHECK(hipStreamSynchronize(p->stream));
-  const int64_t n = std::min<int64_t>(p->stamp_next, cap_records < 0 ? 0 : cap_records);
-  if (n > 0 && out_host) HIPCHECK(hipMemcpy(out_host, p->stamps, size_t(n) * 64, hipMemcpyDeviceToHost));
-  *n_records = p->stamp_next;
-  p->stamp_next = 0;
-  return CWT_OK;
 }
 
 int cwt_plan_last_split(cwt_plan* p, int counts[6]) {

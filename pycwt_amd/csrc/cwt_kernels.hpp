@@ -22,11 +22,6 @@
 #ifndef CWT_MAX_THREADS
 #define CWT_MAX_THREADS 1024
 #endif
-// -DCWT_LAB builds (tools/build_variants.py; never the product library) add the measured-and-rejected kernel variants,
-// the phase stamps and the timing-only ablations that tools/ and DESIGN.md's experiment tables refer to.
-#if defined(CWT_LAB) && !defined(CWT_OLS_ABLATE)
-#define CWT_OLS_ABLATE 0      // timing-only ablations of the overlap-save band kernel: 1 = no FFT, 2 = no stores
-#endif
 // Minimum resident waves per SIMD the compiler must allow for (second __launch_bounds__ argument, i.e. the VGPR
 // budget: 4 -> 128, 5 -> 96, 6 -> 80, 8 -> 64 registers) of the compile-time kernels, per precision.  Measured
 // defaults; override with -D for tuning runs.
@@ -87,6 +82,8 @@ struct RowDesc {
   long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N); rows with tables or coefficient
                    // planes of their own (overlap-save, polynomial): element offset of those
   long aux_off;    // polynomial rows: element offset of the row's filtered band (k_poly_band)
+  double nyq_re;   // k_aols rows of a two-sided real filter (DOG): F_j at the Nyquist bin / N, the one bin outside the mask
+  double nyq_im;   //   and its mirror image
 };
 
 struct Mother {
@@ -103,9 +100,6 @@ struct TwN {
   const cplx<T>* lo;  // lo[i] = e^{2 pi i i / N}, i < (1 << shift)
   int shift;
   __device__ __forceinline__ cplx<T> operator()(unsigned t) const {
-#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
-    return mk<T>(T(1) - T(t) * T(1e-9), T(t) * T(1e-9));   // timing only: no table look-ups
-#endif
     return cmul<T>(hi[t >> shift], lo[t & ((1u << shift) - 1u)]);
   }
 };
@@ -114,9 +108,6 @@ struct TwN {
 // fp64: n = rint(x*log2 e), Cody-Waite reduction to |f| <= ln2/2, degree-13 Taylor polynomial
 // (truncation 4e-18), ldexp; ~19 instructions and 1-2 ulp, against ~40 for the library call.
 __device__ __forceinline__ double exp_(double x) {
-#if defined(CWT_LAB) && defined(CWT_ABLATE_EXP)
-  return 1.0 + x * 1e-3;       // timing only: what the filter evaluation costs
-#endif
   const double n = rint(x * 1.4426950408889634074);
   double f = fma(n, -6.93147180369123816490e-01, x);
   f = fma(n, -1.90821492927058770002e-10, f);
@@ -182,31 +173,6 @@ __device__ __forceinline__ cplx<T> filtered_bin(const cplx<T>* __restrict__ xhat
 
 __device__ __forceinline__ int signed_bin(int k, int N) { return k < (N >> 1) ? k : k - N; }
 
-// Phase stamps (diagnostics only, plan option "stamps"; the STAMP = false instantiations carry none of this):
-// thread 0 of a workgroup records the 100 MHz wall clock at up to 6 points of its life (slot s of its 8-word
-// record), its placement (HW_ID | XCC_ID << 32) in word 6 and its block ids in word 7.  `drain` waits for
-// every outstanding memory operation of the calling wave first, so that the stamp marks data arrival /
-// write acknowledgement rather than instruction issue.
-struct Stamps {
-  unsigned long long* base;
-  unsigned first;             // record index of workgroup (0, 0) of this launch
-};
-template <bool STAMP>
-__device__ __forceinline__ void stamp(const Stamps& st, int slot, bool drain) {
-  if constexpr (STAMP) {
-    if (drain) __builtin_amdgcn_s_waitcnt(0);
-    if (threadIdx.x == 0) {
-      unsigned long long* rec = st.base + 8ull * (st.first + blockIdx.y * gridDim.x + blockIdx.x);
-      rec[slot] = wall_clock64();
-      if (slot == 0) {
-        rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-        rec[7] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 32);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_small: whole transform of length N = 2^logN (16..lmax) inside one workgroup, TB rows per WG.
 // MODE IN_SPECTRUM: rows of W.  MODE IN_REAL: forward FFT of the zero-padded real signal
@@ -245,7 +211,7 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   } else {
     const cplx<T>* xhat = static_cast<const cplx<T>*>(in);
     RowDesc rd;
-    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; rd.aux_off = 0; }
+    if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; rd.aux_off = 0; rd.nyq_re = 0; rd.nyq_im = 0; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = g.j + (e << logNT);
@@ -547,11 +513,7 @@ __device__ __forceinline__ void narrow_phases(const cplx<T>* __restrict__ xhat, 
   for (int idx = threadIdx.x; idx < NTERMS * KQ; idx += (1 << (LOGP - 4))) {
     const int i = idx / KQ, q = PH * KQ + (idx - i * KQ);
     const int dq = (q - rd.k_lo) & (K - 1);
-#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
-    ytile[idx] = mk<T>(T(dq) * T(1e-3), T(i));             // timing only: no spectrum loads, no filter evaluation
-#else
     ytile[idx] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + dq + (i << LOGK), N - 1);
-#endif
   }
   __syncthreads();
 #pragma unroll
@@ -661,82 +623,6 @@ k_narrow_ct_all(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ ro
 #undef CWT_NARROW_CASE
 }
 
-#ifdef CWT_LAB
-// (measured slower than the workgroup kernel in both precisions -- K = 16 ... 128: 2.90 / 3.34 / 3.19 / 3.33 against
-// 2.73 / 3.22 / 3.08 / 3.14 us per row in fp64 -- the barriers are not what these rows wait for, and every wave rebuilds
-// the band; kept for the record, lab builds only)
-// Band-limited rows with K <= 128, one aliased term: the K/16 <= 8 threads of a transform sit in ONE wavefront (lane =
-// thread-in-transform * RW + residue, RW = 64 / (K/16) residues per wave), so the exchange of the radix-16 stage and the
-// build of the filtered band need only wave-level synchronisation: no workgroup barrier anywhere, the 8 (fp64) / 16
-// (fp32) waves of a workgroup run on their own and their compute and store phases interleave freely.  Every wave builds
-// the row's band (K <= 128 bins, at most two filter evaluations per lane) in its own LDS slice, which the exchange then
-// re-uses.  Same grid, same residues per workgroup (8192 / 16384 points) and the same stores as k_narrow_ct_all: a store
-// instruction writes K/16 segments of RW x sizeof(complex) = 1 KiB ... 128 bytes.
-template <typename T, int LOGK, int LOGP>
-__device__ __forceinline__ void narrow_wave_body(const cplx<T>* __restrict__ xhat, const RowDesc& rd, const Mother& mo,
-                                                 const cplx<T>* __restrict__ tw_all, const TwN<T>& twn, int logN,
-                                                 cplx<T>* __restrict__ W, long ldw, long ncols, T* lds_wg) {
-  constexpr int K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, LOGRW = 6 - LOGNT, RW = 1 << LOGRW;
-  constexpr int LOGWAVES = LOGP - 10;                       // waves per workgroup: 2^(LOGP - 4) threads / 64
-  static_assert(LOGK >= 4 && LOGK <= 7, "K = 16 .. 128");
-  using F = ct::Fft<T, LOGK, LOGRW, true, false, true>;
-  const int N = 1 << logN, logR = logN - LOGK;
-  const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
-  T* lds = lds_wg + wave * (K * RW);                        // this wave's slice: K * RW = 1024 reals
-  F f;
-  f.t = lane & (RW - 1);
-  f.j = lane >> LOGRW;
-  const unsigned r = (((xcd_tile<T>() << LOGWAVES) + unsigned(wave)) << LOGRW) + unsigned(f.t);
-  cplx<T>* ytile = reinterpret_cast<cplx<T>*>(lds);
-  for (int q = lane; q < K; q += 64) {
-    const int dq = (q - rd.k_lo) & (K - 1);
-    ytile[q] = filtered_bin<T>(xhat, rd, mo, rd.k_lo + dq, N - 1);
-  }
-  F::sync();
-  const unsigned nm = unsigned(N - 1);
-  const cplx<T> step = twn((unsigned(NT) * r) & nm);
-  const cplx<T> rho = twn((r << LOGK) & nm);
-  const cplx<T> stepw = cmul<T>(step, mk<T>(rho.x, -rho.y));
-  int d = (f.j - rd.k_lo) & (K - 1);
-  cplx<T> cur = twn((unsigned(rd.k_lo + d) * r) & nm);
-  T re[16], im[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const cplx<T> y = ytile[f.j + e * NT];
-    re[e] = y.x * cur.x - y.y * cur.y;
-    im[e] = y.x * cur.y + y.y * cur.x;
-    const int dn = (d + NT) & (K - 1);
-    cur = cmul<T>(cur, dn < d ? stepw : step);
-    d = dn;
-  }
-  F::sync();                                                // the band aliases the exchange slice
-  f.run(re, im, lds, tw_all + (K - 2));
-  cplx<T>* wrow = W + long(rd.out_row) * ldw;
-  const unsigned off = (unsigned(f.j) << logR) + r;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const unsigned step_e = unsigned(e * NT) << logR;
-    if (long(off) + step_e < ncols) store_w<T>(wrow + step_e + off, re[e], im[e]);
-  }
-}
-
-template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_NARROW_F64 : CWT_LB_NARROW_F32))
-k_narrow_wave(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
-              const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
-  HIP_DYNAMIC_SHARED(double2, lds_raw)
-  T* lds = reinterpret_cast<T*>(lds_raw);
-  const RowDesc rd = rows[blockIdx.y];
-  switch (rd.logK) {
-    case 4: narrow_wave_body<T, 4, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
-    case 5: narrow_wave_body<T, 5, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
-    case 6: narrow_wave_body<T, 6, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
-    case 7: narrow_wave_body<T, 7, LOGP>(xhat, rd, mo, tw_all, twn, logN, W, ldw, ncols, lds); break;
-    default: break;
-  }
-}
-
-#endif  // CWT_LAB
 
 // Band-limited rows with 5..16 aliased terms of K = 1024 bins (support up to 16384 bins): a kernel of their own so
 // that the common cases above keep their register allocation.
@@ -891,31 +777,27 @@ __device__ __forceinline__ void pass_a_band_body(const cplx<T>* __restrict__ xha
 
 // Pass A of a chunk of wide rows: every workgroup branches once on its row's class (rd.logK: 0 = all
 // R inputs may be non-zero -> full column FFT; 4/6/8 -> support spans <= 16/64/256 bins k1).
-template <typename T, int LOGR, int LOGP, bool STAMP = false>
+template <typename T, int LOGR, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_A_F64 : CWT_LB_PASS_A_F32))
 k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, Mother mo,
-                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ Z, Stamps st) {
+                 const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, cplx<T>* __restrict__ Z) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
-  stamp<STAMP>(st, 0, false);
   const RowDesc rd = rows[blockIdx.y];
   cplx<T>* z = Z + (long(blockIdx.y) << logN);
   if constexpr (LOGR > 4)
     if (rd.logK == 4) {
       pass_a_band_body<T, LOGR, LOGP, 4>(xhat, rd, mo, tw_all, twn, logN, z, lds);
-      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
       return;
     }
   if constexpr (LOGR > 6)
     if (rd.logK == 6) {
       pass_a_band_body<T, LOGR, LOGP, 6>(xhat, rd, mo, tw_all, twn, logN, z, lds);
-      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
       return;
     }
   if constexpr (LOGR > 8)
     if (rd.logK == 8) {
       pass_a_band_body<T, LOGR, LOGP, 8>(xhat, rd, mo, tw_all, twn, logN, z, lds);
-      stamp<STAMP>(st, 3, false); stamp<STAMP>(st, 4, true);
       return;
     }
   // full column FFT (same code as k_pass_a_ct<..., IN_SPECTRUM>)
@@ -934,27 +816,21 @@ k_pass_a_ct_rows(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ r
     const cplx<T> v = filtered_bin<T>(xhat, rd, mo, signed_bin(k, N), N - 1);
     re[e] = v.x; im[e] = v.y;
   }
-  stamp<STAMP>(st, 1, true);
   f.run(re, im, lds, tw_all + ((1 << LOGR) - 2));
-  stamp<STAMP>(st, 2, false);
   const unsigned off = (unsigned(f.j) << logK) + q;
 #pragma unroll
   for (int e = 0; e < 16; ++e) (z + (long(e * NT) << logK))[off] = mk<T>(re[e], im[e]);
-  stamp<STAMP>(st, 3, false);
-  stamp<STAMP>(st, 4, true);
 }
 
-template <typename T, int LOGK, int LOGP, bool CONJ, bool STAMP = false>
+template <typename T, int LOGK, int LOGP, bool CONJ>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? CWT_LB_PASS_B_F64 : CWT_LB_PASS_B_F32))
 k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols,
-            Stamps st) {
+            const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT, BD = 1 << (LOGP - 4);
   using F = ct::Fft<T, LOGK, LOGTB, false>;
   const int logR = logN - LOGK;
-  stamp<STAMP>(st, 0, false);
   F f;
   f.j = threadIdx.x & (NT - 1);
   f.t = threadIdx.x >> LOGNT;
@@ -967,78 +843,15 @@ k_pass_b_ct(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
     const cplx<T> v = (z + e * NT)[zoff];
     re[e] = v.x; im[e] = v.y;
   }
-  stamp<STAMP>(st, 1, true);
   twiddle_slots<T>(re, im, twn((r0 + unsigned(f.t)) * unsigned(f.j)), twn((r0 + unsigned(f.t)) << LOGNT));
 #pragma unroll
   for (int e = 0; e < 16; ++e) { keep_here(re[e]); keep_here(im[e]); }   // twiddle done before the FFT's registers fill up
   f.run(re, im, lds, tw);
-  stamp<STAMP>(st, 2, false);
 
   const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
   transpose_store<T, LOGK, LOGP, CONJ>(re, im, lds, f.t, f.j, W + orow * ldw, logR, r0, ncols);
-  stamp<STAMP>(st, 3, false);
-  stamp<STAMP>(st, 4, true);
 }
 
-#ifdef CWT_LAB
-// Pass B with the loads of the next tile in flight under the FFT and the stores of the current one (option
-// "pass_b_prefetch"): every workgroup walks NTILES tiles of its row (tile v = blockIdx.x + i * gridDim.x, the same
-// XCD slice under the XCD-aware map), holding two register sets; one workgroup per CU instead of two.
-template <typename T, int LOGK, int LOGP, int NTILES>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? 2 : 4))
-k_pass_b_ct_pf(const cplx<T>* __restrict__ Z, const RowDesc* __restrict__ rows,
-               const cplx<T>* __restrict__ tw, TwN<T> twn, int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
-  HIP_DYNAMIC_SHARED(double2, lds_raw)
-  T* lds = reinterpret_cast<T*>(lds_raw);
-  constexpr int LOGTB = LOGP - LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
-  using F = ct::Fft<T, LOGK, LOGTB, false>;
-  const int logR = logN - LOGK;
-  F f;
-  f.j = threadIdx.x & (NT - 1);
-  f.t = threadIdx.x >> LOGNT;
-  const unsigned ntiles = gridDim.x * NTILES;
-  auto tile_r0 = [&](int i) {
-    const unsigned v = blockIdx.x + unsigned(i) * gridDim.x;
-    const unsigned x = (sizeof(T) == 8 && !(ntiles & 7u)) ? (v & 7u) * (ntiles >> 3) + (v >> 3) : v;
-    return x << LOGTB;
-  };
-  const cplx<T>* zrow = Z + (long(blockIdx.y) << logN);
-  const unsigned zoff = (unsigned(f.t) << LOGK) + f.j;
-  const long orow = rows ? long(rows[blockIdx.y].out_row) : long(blockIdx.y);
-  cplx<T>* wrow = W + orow * ldw;
-  T ar[16], ai[16], br[16], bi[16];
-  {
-    const cplx<T>* z = zrow + (long(tile_r0(0)) << LOGK);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; ar[e] = v.x; ai[e] = v.y; }
-  }
-#pragma unroll
-  for (int i = 0; i < NTILES; i += 2) {
-    if (i + 1 < NTILES) {
-      const cplx<T>* z = zrow + (long(tile_r0(i + 1)) << LOGK);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; br[e] = v.x; bi[e] = v.y; }
-    }
-    twiddle_slots<T>(ar, ai, twn((tile_r0(i) + unsigned(f.t)) * unsigned(f.j)), twn((tile_r0(i) + unsigned(f.t)) << LOGNT));
-    f.run(ar, ai, lds, tw);
-    transpose_store<T, LOGK, LOGP, false>(ar, ai, lds, f.t, f.j, wrow, logR, tile_r0(i), ncols);
-    __syncthreads();                                     // LDS is reused by the next tile's FFT
-    if (i + 1 < NTILES) {
-      if (i + 2 < NTILES) {
-        const cplx<T>* z = zrow + (long(tile_r0(i + 2)) << LOGK);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { const cplx<T> v = (z + e * NT)[zoff]; ar[e] = v.x; ai[e] = v.y; }
-      }
-      twiddle_slots<T>(br, bi, twn((tile_r0(i + 1) + unsigned(f.t)) * unsigned(f.j)),
-                       twn((tile_r0(i + 1) + unsigned(f.t)) << LOGNT));
-      f.run(br, bi, lds, tw);
-      transpose_store<T, LOGK, LOGP, false>(br, bi, lds, f.t, f.j, wrow, logR, tile_r0(i + 1), ncols);
-      __syncthreads();
-    }
-  }
-}
-
-#endif  // CWT_LAB
 
 // =============================================================================================
 // Overlap-save rows (k_ols_fwd, k_ols_ct): wide-band rows whose wavelet is COMPACT IN TIME.
@@ -1121,73 +934,6 @@ __global__ void k_ols_gtab(const RowDesc* __restrict__ rows, Mother mo, int logP
   gt[rd.tab_off + q] = g;
 }
 
-#ifdef CWT_LAB
-// Half spectra of the input blocks of the classes with block length P_b = 2^(LOGM + LOGD) on M = 2^LOGM-point
-// workgroup tiles.  LOGD = 0: one workgroup = one block.  LOGD = 1: the first radix-2 step of a decimation-in-frequency
-// transform is done while loading -- workgroup (block, c) computes the bins 2k + c as the M-point transform of
-// x0 + x1 (c = 0: real input again) or (x0 - x1) e^{-2 pi i n / P_b} (c = 1), x0 / x1 = the two halves of the block --
-// so that double-length blocks run on the same 8192-point tiles as everything else (a 16384-point workgroup holds one
-// tile per CU and measured 80 us for 340 blocks).  Only bins <= P_b / 2 are kept (x is real).
-template <typename T, int LOGM, int LOGD>
-__global__ void __launch_bounds__(1 << (LOGM - 4), 4)
-k_ols_fwd(const T* __restrict__ x, long n0, int logN, OlsClasses cls, const cplx<T>* __restrict__ tw_all, TwN<T> twn,
-          cplx<T>* __restrict__ xs) {
-  HIP_DYNAMIC_SHARED(double2, lds_raw)
-  T* lds = reinterpret_cast<T*>(lds_raw);
-  constexpr int M = 1 << LOGM, NT = M >> 4, LOGB = LOGM + LOGD, PB = 1 << LOGB;
-  using F = ct::Fft<T, LOGM, 0, false>;
-  const int wg = int(blockIdx.x) >> LOGD, part = int(blockIdx.x) & ((1 << LOGD) - 1);
-  int c = 0;
-  for (int i = 0; i < cls.n; ++i)
-    if (cls.c[i].logb == LOGB && wg >= cls.c[i].blk_first) c = i;
-  const int blk = wg - cls.c[c].blk_first, H = cls.c[c].halo, L = PB - 2 * H;
-  const long nmask = (1L << logN) - 1;
-  const long first = long(blk) * L - H;
-  F f;
-  f.t = 0;
-  f.j = threadIdx.x;
-  T re[16], im[16];
-  if constexpr (LOGD == 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long n = (first + f.j + e * NT) & nmask;
-      re[e] = n < n0 ? x[n] : T(0);
-      im[e] = T(0);
-    }
-  } else {
-    static_assert(LOGD == 1, "one radix-2 step");
-    T a[16], b[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long na = (first + f.j + e * NT) & nmask, nb = (first + M + f.j + e * NT) & nmask;
-      a[e] = na < n0 ? x[na] : T(0);
-      b[e] = nb < n0 ? x[nb] : T(0);
-    }
-    if (part == 0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { re[e] = a[e] + b[e]; im[e] = T(0); }
-    } else {
-      // the engine runs the inverse direction: conj(input) = (x0 - x1) e^{+2 pi i n / P_b}, n = j + e NT
-      const int sh = logN - LOGB;
-      cplx<T> cur = twn(unsigned(f.j) << sh);
-      const cplx<T> step = twn(unsigned(NT) << sh);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const T d = a[e] - b[e];
-        re[e] = d * cur.x; im[e] = d * cur.y;
-        if (e < 15) cur = cmul<T>(cur, step);
-      }
-    }
-  }
-  f.run(re, im, lds, tw_all + (M - 2));
-  cplx<T>* out = xs + cls.c[c].xs_off + long(blk) * ((PB >> 1) + 8);
-  // bin (k << LOGD) + part, k = j + e NT, kept while <= P_b / 2: forward = conj(inverse(conj input))
-#pragma unroll
-  for (int e = 0; e < 8; ++e) out[((f.j + e * NT) << LOGD) + part] = mk<T>(re[e], -im[e]);
-  if (f.j == 0 && part == 0) out[PB / 2] = mk<T>(re[8], -im[8]);
-}
-
-#endif  // CWT_LAB
 
 // Half spectra X_b[0 .. P_b/2] of the input blocks of the overlap-save classes (x is real), from a complex transform of
 // HALF the block length (the classic real-input packing): with
@@ -1309,12 +1055,8 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
   for (int i = 0; i < NQ; ++i) {
     const int q = int(threadIdx.x) + i * BD;
     if (q < K) {
-#if defined(CWT_LAB) && defined(CWT_ABLATE_PROLOGUE)
-      yv[i] = mk<T>(T(q) * T(1e-3), T(1)); gv[i] = mk<T>(T(1), T(q) * T(1e-4));   // timing only: no band / table loads
-#else
       yv[i] = ols_load<T>(xb, rd, rd.k_lo + ((q - rd.k_lo) & (K - 1)));
       gv[i] = gt[q];
-#endif
     }
   }
 #pragma unroll
@@ -1337,25 +1079,15 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
     re[e] = y.x * cur.x - y.y * cur.y;
     im[e] = y.x * cur.y + y.y * cur.x;
     if (e < 15) cur = cmul<T>(cur, step);
-#if !(defined(CWT_LAB) && defined(CWT_ABLATE_WRAP))                      // (timing-only lab ablation: no alias wrap)
     if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
-#endif
   }
   __syncthreads();                                       // the band tile aliases the exchange buffer
-#if !defined(CWT_LAB) || CWT_OLS_ABLATE != 1
   f.run(re, im, lds, tw_all + (K - 2));
-#endif
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     // n_local = (P_b / K) (j + e NT) + r; with P_b = P this is thread + e P/16
     const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
-#if defined(CWT_LAB) && CWT_OLS_ABLATE == 2
-    if (nl >= 0 && nl < nlim && re[e] == T(-1.2345e-300)) store_w<T>(wout + nl, re[e], im[e]);
-#elif defined(CWT_LAB) && defined(CWT_ABLATE_PRED)
-    store_w<T>(wout + max(0, min(nl, nlim - 1)), re[e], im[e]);        // timing only: clamped index, no predicated store
-#else
     if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
-#endif
   }
 }
 
@@ -1420,6 +1152,10 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
 // band-passed signal x_M = IFFT_N(xhat mask), which is computed ONCE per transform (one two-pass row) and shared by all
 // such rows.  Valid because xhat mask vanishes wherever E_j differs from F_j: Morlet's negative-frequency part (below the
 // support threshold from bin k_s down), Paul's Heaviside (k_s = 1).
+// DOG (two-sided real profile P(-f) = (-1)^m P(f), real signal): with the mask over the positive bins 1 .. N/2 - 1 and
+// y = x_M (*) e_j (table = sign |amp| P u), the negative bins contribute (-1)^m conj: W = 2 Re y (m even) or -2 Im y (m odd,
+// amp = i sign |amp|), plus the Nyquist bin, which the reference counts once, at -pi / dt: + F_j[N/2] xhat[N/2] (-1)^n / N
+// (RowDesc::nyq_*).  RowDesc::nterms of such a row: 1 = y itself, 2 = 2 Re y, 3 = -2 Im y.
 struct AolsGeom {
   int nrows;       // rows of the class
   int nblocks;     // output blocks of L = P - 2 halo columns
@@ -1488,7 +1224,8 @@ template <typename T, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64)
                                                                 : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
 k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const T* __restrict__ gtab,
-            const cplx<T>* __restrict__ tw_all, AolsGeom g, cplx<T>* __restrict__ W, long ldw, long ncols) {
+            const cplx<T>* __restrict__ tw_all, AolsGeom g, const cplx<T>* __restrict__ xhat_nyq, cplx<T>* __restrict__ W,
+            long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int P = 1 << LOGP, NT = P >> 4;
@@ -1516,10 +1253,22 @@ k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, co
 #pragma unroll
   for (int e = 0; e < 16; ++e) { re[e] *= gv[e]; im[e] *= gv[e]; }
   f.run(re, im, lds, tw_all + (P - 2));
+  if (rd.nterms == 1) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int nl = f.j + e * NT - H;
-    if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+    for (int e = 0; e < 16; ++e) {
+      const int nl = f.j + e * NT - H;
+      if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+    }
+  } else {                                                // two-sided real filter of a real signal (see above)
+    const cplx<T> xn = *xhat_nyq;
+    const T nr = T(rd.nyq_re) * xn.x - T(rd.nyq_im) * xn.y, ni = T(rd.nyq_re) * xn.y + T(rd.nyq_im) * xn.x;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int nl = f.j + e * NT - H;
+      const T v = rd.nterms == 2 ? T(2) * re[e] : T(-2) * im[e];
+      const T sg = ((col0 + nl) & 1) ? T(-1) : T(1);      // (-1)^n
+      if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, v + sg * nr, sg * ni);
+    }
   }
 }
 

@@ -65,11 +65,7 @@ __device__ __forceinline__ void keep_here(T& v) {
 // stage twiddle e^{2 pi i idx / L} from the table (timing-only lab ablation: arithmetic instead of the load)
 template <typename T>
 __device__ __forceinline__ cplx<T> stage_tw(const cplx<T>* __restrict__ tw, int idx) {
-#if defined(CWT_LAB) && defined(CWT_ABLATE_STAGE_TW)
-  return mk<T>(T(1) - T(idx) * T(1e-9), T(idx) * T(1e-9));
-#else
   return tw[idx];
-#endif
 }
 
 template <typename T>
@@ -197,11 +193,7 @@ __device__ __forceinline__ void twiddle_chain(T (&re)[R], T (&im)[R], T wr, T wi
     const T x = re[m], y = im[m];
     re[m] = x * pr - y * pi;
     im[m] = x * pi + y * pr;
-#if defined(CWT_LAB) && defined(CWT_ABLATE_TW)
-    if (false) {                 // timing only: what the running-product twiddles cost
-#else
     if (m + 1 < R) {
-#endif
       const T nr = pr * wr - pi * wi;
       pi = pr * wi + pi * wr;
       pr = nr;
@@ -359,19 +351,8 @@ struct Fft {
     constexpr int LOGNS = 4 * S;
     const int k = j & ((1 << LOGNS) - 1);
     if constexpr (S > 0) {
-#if defined(CWT_LAB) && defined(CWT_TW_TABLE)
-      // experiment: the 15 powers w^m from the table (15 loads through the idle texture path) instead of a running product
-#pragma unroll
-      for (int m = 1; m < 16; ++m) {
-        const cplx<T> w = tw[(k * m) << (LOGL - LOGNS - 4)];
-        const T x = re[m], y = im[m];
-        re[m] = x * w.x - y * w.y;
-        im[m] = x * w.y + y * w.x;
-      }
-#else
       const cplx<T> w = stage_tw<T>(tw, k << (LOGL - LOGNS - 4));
       twiddle_chain<T, 16>(re, im, w.x, w.y);
-#endif
     }
     bfly16<T>(re, im);
     if constexpr (S == NFULL - 1 && REM == 0) return;

@@ -59,3 +59,16 @@ def test_multi_rank_launch_as_the_driver_does(emu_library, world):
     assert d["weak_scaling"]["rows_total"] == 12 * world and d["weak_scaling"]["rows_per_gpu"] == 12
     assert "parity" not in d and "cpu_baseline" not in d          # rank 0 at N = 1 only
     assert d["value"] > 0 and d["weak_scaling"]["value"] > 0
+
+
+def test_plain_multi_gpu_command_spawns_its_own_ranks(emu_library):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's single-GPU command): bench.py starts its
+    ranks itself through torch.distributed.run on the loopback address and still prints exactly one JSON line."""
+    env_keys = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        d = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--emulate", "--backend", "gloo",
+                 "--logn", "13", "--rows", "12"])
+    finally:
+        os.environ.update(saved)
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 6 and d["value"] > 0

@@ -153,12 +153,27 @@ def test_few_clipped_rows_stay_two_pass(emu_library):
     assert split["aols"] == 2 and split["two_pass"] == 0, classes
 
 
-def test_dog_rows_clipped_at_nyquist_stay_two_pass(emu_library):
-    """DOG filters are two-sided: nothing to mask out; those rows keep the N-point transform."""
-    N = 1 << 15
-    x = np.random.default_rng(3).standard_normal(N)
-    m = orc.Mother(orc.DOG, 2)
-    sj = grid(N, 1.0, m, 32)
-    W, split, _ = transform(emu_library, N, x, orc.DOG, 2, sj, 64, {"ols_min_logn": 15})
-    assert split["aols"] == 0 and split["two_pass"] > 0
-    assert row_errors(W, orc.cwt_rows(x, 1.0, sj, m))[0].max() < TOL[64]
+@pytest.mark.parametrize("m_order,prec,logn,n0_off", [(2, 64, 15, 0), (2, 32, 16, 333), (1, 64, 15, 1), (3, 64, 15, 7), (6, 32, 15, 0)])
+def test_dog_rows_clipped_at_nyquist(emu_library, m_order, prec, logn, n0_off):
+    """DOG filters are two-sided and real: with the REAL signal at hand (cwt_transform) the positive bins are masked, the
+    negative ones are their mirror image (W = 2 Re y for even orders, -2 Im y for odd ones) and the Nyquist bin, which the
+    reference counts once at -pi/dt, is added by the kernel.  From the spectrum alone (cwt_transform_rows: the spectrum
+    might belong to a complex signal) those rows keep the N-point transform."""
+    N = 1 << logn
+    n0 = N - n0_off
+    x = np.random.default_rng(3).standard_normal(n0)
+    m = orc.Mother(orc.DOG, m_order)
+    sj = grid(n0, 1.0, m, 48)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
+    opts = {"ols_min_logn": 15, "poly": 0}
+    W, split, classes = transform(emu_library, N, x, orc.DOG, m_order, sj, prec, opts)
+    W0, split0, _ = transform(emu_library, N, x, orc.DOG, m_order, sj, prec, dict(opts, aols=0))
+    assert split0["aols"] == 0 and split0["two_pass"] >= 3
+    assert split["aols"] >= 3 and split["two_pass"] < split0["two_pass"], (split, split0)
+    bar = 20 * TOL[prec] if prec == 64 else TOL[prec]
+    per_row, _ = row_errors(W, ref)
+    assert per_row.max() < bar, (per_row.argmax(), per_row.max(), classes[per_row.argmax()])
+    assert np.abs(W.imag).max() <= (1e-12 if prec == 64 else 1e-4) * np.abs(W).max() or m_order % 2      # even orders: W is real
+    W1, split1, _ = transform(emu_library, N, x, orc.DOG, m_order, sj, prec, opts, with_signal=False)
+    assert split1["aols"] == 0 and split1["two_pass"] >= split0["two_pass"]      # (no overlap-save rows either without the signal)
+    assert row_errors(W1, ref)[0].max() < bar
