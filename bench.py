@@ -235,7 +235,7 @@ class Workload:
             if spent >= min_ms or done >= 4096:
                 return done
 
-    def roofline(self, steps):
+    def roofline(self, steps, traffic=None):
         """Per-kernel HIP-event timing in separate passes (option "profile": every kernel alone on the plan's
         stream, so that each duration is its own) -> achieved algorithmic bandwidth of every kernel class and of the
         whole path; `frac` etc. describe the class with the largest total time (the "dominant kernel")."""
@@ -272,8 +272,10 @@ class Workload:
         traffic_file, traffic_tab = None, {}
         tpath = os.path.join(ROOT, "profiles", f"traffic_{self.config}.json")
         default_opts = set(self.opts) <= {"tolerance"} and self.opts.get("tolerance") == BENCH_TOLERANCE[self.prec]
-        if os.path.exists(tpath) and default_opts and N == 1 << 20 and self.rows_total == 256 and rt.shard == (0, 1):
-            traffic_file = f"profiles/traffic_{self.config}.json"
+        if traffic:
+            traffic_file, traffic_tab = traffic["source"], traffic["per_kernel_class"]
+        elif os.path.exists(tpath) and default_opts and N == 1 << 20 and self.rows_total == 256 and rt.shard == (0, 1):
+            traffic_file = f"builder_profile: profiles/traffic_{self.config}.json (committed PMC passes of the same command)"
             traffic_tab = json.load(open(tpath))["per_kernel_class"]
         per_class = {}
         for name, (kernels, rows) in groups.items():
@@ -300,6 +302,7 @@ class Workload:
         achieved = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
         gpu_ms = sum(v["ms_per_step"] for v in kern.values())
         alg_bytes_total = float(N) * len(self.sj) * self.csize + N * (self.csize // 2)
+        traffic_cal = traffic.get("calibration") if isinstance(traffic, dict) else None
         traffic = traffic_tab.get(dom_kernel, {}).get("hbm_bytes_per_launch")
         whole = {"algorithmic_bytes_per_step_per_gpu": alg_bytes_total, "kernel_ms_per_step": gpu_ms,
                  "achieved_GBs": alg_bytes_total / (gpu_ms * 1e-3) / 1e9,
@@ -312,9 +315,10 @@ class Workload:
             # sum of all kernel times of the profiling pass)
             "whole_path_frac": whole["frac"],
             "traffic": traffic,
-            # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this command, collected
-            # by the builder and committed -- NOT measured inside this run
-            "traffic_source": ("builder_profile: " + traffic_file) if traffic else None,
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes): measured inside
+            # this run by live_traffic() where rocprofv3 is available, else the builder's committed passes of the same command
+            "traffic_source": traffic_file if traffic else None,
+            "traffic_calibration": traffic_cal,
             "avg_launch_ms": dom_avg_ms, "launches_per_step": dom_launches,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "traffic_GBs": (traffic / (dom_avg_ms * 1e-3) / 1e9) if traffic else None,
@@ -526,6 +530,90 @@ def config4_batch(rt, steps=3):
             "parity_all_rows": "tests/test_gpu_parity.py::test_config4_full_batch_* (sampled pairs + Parseval on all 131072 rows)"}
 
 
+
+def kernel_class(name):
+    """rocprofv3 kernel name -> the kernel class names of cwt_plan_timings (the mask pass of the aols rows runs the two-pass
+    kernels and is counted with them)."""
+    n = name.replace("void cwt::", "").replace("cwt::", "")
+    table = (("k_poly_rows", "poly"), ("k_poly_coef", "poly_coef"), ("k_poly_band", "poly_coef"), ("k_aols_rows", "aols"),
+             ("k_aols_fwd", "aols_pre"), ("k_ols_fwd", "ols_fwd"), ("k_narrow_ct_big", "narrow_big"),
+             ("k_narrow_ct_many", "narrow_many"), ("k_narrow", "narrow"), ("k_icwt", "icwt"), ("k_small", "small"))
+    for prefix, cls in table:
+        if n.startswith(prefix):
+            return cls
+    if n.startswith("k_ols_ct"):
+        return "ols_small" if n.split("(")[0].rstrip(">").endswith(", 12") else "ols"
+    if n.startswith("k_pass_a_ct_rows") or n.startswith("k_pass_a<"):
+        return "pass_a"
+    if n.startswith("k_pass_a_ct"):
+        return "fwd_pass_a"
+    if n.startswith("k_pass_b"):
+        args = n[n.find("<") + 1:n.find(">")].split(", ")
+        return "fwd_pass_b" if args[-1] == "true" else "pass_b"
+    return None
+
+
+def live_traffic(config, logn, rows, n_poly, csize):
+    """HBM traffic of every kernel class from PMC counters, measured INSIDE this run: two short child runs of this script
+    under `rocprofv3 --kernel-trace --pmc <counter>` (one counter per pass, kernels serialized), as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950.  Both counters
+    are then CALIBRATED on kernels of this very run whose byte counts are known exactly and whose access pattern is the
+    path's own: WRITE_SIZE on k_poly_rows (non-temporal 16-byte stores: n_poly x N x sizeof(complex) bytes written), FETCH_SIZE
+    on k_icwt (reads every element of W once).  Returns None when rocprofv3 is not available or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    sums, counts = {}, {}
+    tmp = tempfile.mkdtemp(prefix="cwt_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "cwt", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", config, "--logn", str(logn), "--rows", str(rows),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-prime", "--no-live-traffic",
+                   "--opt", "overlap_narrow=0", "--opt", "ols_early=0", "--opt", "ols_side=0"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    cls = kernel_class(row["Kernel_Name"])
+                    if cls and row["Counter_Name"] == counter:
+                        sums[(cls, counter)] = sums.get((cls, counter), 0.0) + float(row["Counter_Value"])
+                        counts[(cls, counter)] = counts.get((cls, counter), 0) + 1
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per = {}
+    for (cls, counter), tot in sums.items():
+        d = per.setdefault(cls, {})
+        raw = tot * 1024.0 / counts[(cls, counter)] * (2.0 if counter == "FETCH_SIZE" else 1.0)
+        d["fetch_raw" if counter == "FETCH_SIZE" else "write_raw"] = raw
+    N = float(1 << logn)
+    cal = {"write": None, "fetch": None}
+    if n_poly and "poly" in per and per["poly"].get("write_raw"):
+        cal["write"] = n_poly * N * csize / per["poly"]["write_raw"]
+    if "icwt" in per and per["icwt"].get("fetch_raw"):
+        cal["fetch"] = rows * N * csize / per["icwt"]["fetch_raw"]
+    fw, ff = cal["write"] or 1.0, cal["fetch"] or 1.0
+    for cls, d in per.items():
+        d["write_bytes_per_launch"] = d.get("write_raw", 0.0) * fw
+        d["fetch_bytes_per_launch"] = d.get("fetch_raw", 0.0) * ff
+        d["hbm_bytes_per_launch"] = d["write_bytes_per_launch"] + d["fetch_bytes_per_launch"]
+    return {"per_kernel_class": per,
+            "calibration": {"WRITE_SIZE_factor": cal["write"], "FETCH_SIZE_x2_factor": cal["fetch"],
+                            "on": "k_poly_rows (exact output bytes, nt 16-B stores) / k_icwt (exact input bytes)"},
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, serialized "
+                      "kernels, 3 steps each), KiB units, FETCH_SIZE x2 (gfx950), calibrated as stated"}
+
 PRIME_MS = 80.0     # untimed device work before the W warm-up steps, see prime()
 
 
@@ -546,7 +634,16 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
     else:
         out = wl.timed(args.steps, args.warmup)
         out["effective_warmup_steps"] = args.warmup
-    out["roofline"] = wl.roofline(args.steps)
+    traffic = None
+    if (args.live_traffic and not args.emulate and not wl.sharded and not rt.use_dist and not args.shard and want_cpu
+            and set(wl.opts) <= {"tolerance"} and config == args.config and wl.tolerance == BENCH_TOLERANCE[wl.prec]):
+        split = wl.plan.last_split()
+        traffic = live_traffic(config, args.logn, rows_total, split.get("poly", 0), wl.csize)
+    if not wl.sharded and not rt.use_dist and not args.emulate:
+        wl.run_steps(1)
+        rt.fence()
+        out["icwt"] = wl.icwt_pass()
+    out["roofline"] = wl.roofline(args.steps, traffic)
     wp = out["roofline"].get("whole_path")
     if wp:
         # the headline fraction: this GPU's algorithmic bytes of a step over the TIMED step (wall clock of the K steps);
@@ -559,8 +656,6 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
     if want_cpu:
         wl.run_steps(1)
         rt.fence()
-        if not args.emulate:
-            out["icwt"] = wl.icwt_pass()
         out["cpu_baseline"], out["parity"] = wl.cpu_and_parity()
         out["cpu_baseline"]["reference_as_is"] = wl.reference_as_is()
         out["cpu_baseline"]["reference_mounted"] = out["cpu_baseline"]["reference_as_is"]["reference_mounted"]
@@ -596,6 +691,8 @@ def main():
     ap.add_argument("--no-prime", dest="prime", action="store_false",
                     help="do not bring the device to its sustained clocks before the W warm-up steps (then `value` is what "
                          "`from_idle` reports otherwise)")
+    ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
+                    help="do not measure the HBM traffic with rocprofv3 PMC passes inside this run (two short child runs)")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()

@@ -2749,7 +2749,11 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!rc && W_host) rc = grow(&p->hW, &p->hW_bytes, size_t(nrows) * size_t(n0) * 2 * es, p->stream);
   if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(p->hx, x_host, size_t(n0) * es, hipMemcpyHostToDevice, p->stream));
-  if (W_host && p->auto_target > 0) {
+  if (W_host && p->auto_target > 0 && p->logN <= p->loglmax) {
+    // single-workgroup transforms compute every bin of every row anyway: round-off costs nothing, no need to look
+    const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
+    if (floor_tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = floor_tol; }
+  } else if (W_host && p->auto_target > 0) {
     // accuracy target of THIS call = auto_target / (dynamic range of its spectrum relative to white noise), a power of
     // ten (so that calls with like spectra share one cached row table), never looser than the target itself
     rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);

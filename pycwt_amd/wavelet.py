@@ -119,7 +119,7 @@ def _transform(plan, x_host, xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr):
     drop-in, such signals go through the spectrum-only entry points (`cwt_forward_fft` + `cwt_transform_rows`, which
     never use the overlap-save form); the O(N) host scan is free next to the PCIe transfer of W."""
     if np.isfinite(x_host).all():
-        target = _auto(plan)
+        target = _auto(plan) if plan.nfft > 4096 else 0.0     # (single-workgroup transforms: round-off costs nothing)
         if target:      # automatic accuracy: the tolerance of this call from the dynamic range of its spectrum
             plan.forward_fft(xd_ptr, n0, xh_ptr)
             mx, _, floor = plan.spectrum_range(xh_ptr, plan.nfft)
