@@ -193,6 +193,7 @@ struct cwt_plan {
   int poly = 1;            // band-limited rows in polynomial form (k_poly_coef + k_poly_rows) where they fit
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
+  int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
@@ -267,7 +268,8 @@ struct cwt_plan {
     // band-limited rows in polynomial form (at the end of the table), grouped by K'
     int n_poly = 0, poly_first = 0;
     PolyClasses poly_cls{};
-    long poly_wgs = 0, poly_coef_elems = 0, poly_band_elems = 0;
+    long poly_wgs[3] = {0, 0, 0};         // workgroups of the k_poly_coef launches on 4096- / 8192- / 16384-point tiles
+    long poly_coef_elems = 0, poly_band_elems = 0;
     int poly_max_logk = 8;
     int n_aols = 0, aols_first = 0, aux_first = -1, aols_logp = 12;
     AolsGeom aols_geom{};
@@ -294,7 +296,7 @@ struct cwt_plan {
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
-  hipEvent_t ev_ols = nullptr;
+  hipEvent_t ev_ols = nullptr, ev_coef = nullptr;
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
   hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
@@ -810,7 +812,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       // complex64: a lane stores two outputs), degree D from the filter-weighted truncation rule
       int poly_logk = 0, poly_deg = 0;
       if (poly_ok && rd.nband > 0) {
-        const int lk_max = std::min(14, p->logN - POLY_MIN_LOGR);
+        const int lk_max = std::min(p->poly_max_logk, p->logN - POLY_MIN_LOGR);
         const int kc = rd.k_lo + (rd.nband >> 1);
         for (int lk = std::max(8, ilog2(rd.nband)); lk <= lk_max; ++lk) {
           const int deg = poly_degree_for(mother, param, rd.a, kc, rd.k_lo, rd.nband, lk, row_best, tol.support);
@@ -1099,12 +1101,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   p->rt->poly_first = int(p->rt->table.size());
   p->rt->n_poly = int(poly_rows.size());
   p->rt->poly_cls.n = 0;
-  p->rt->poly_wgs = p->rt->poly_coef_elems = 0;
+  p->rt->poly_wgs[0] = p->rt->poly_wgs[1] = p->rt->poly_wgs[2] = 0;
+  p->rt->poly_coef_elems = 0;
   if (!poly_rows.empty()) {
     std::stable_sort(poly_rows.begin(), poly_rows.end(), [](const RowDesc& x, const RowDesc& y) {
       return x.logK != y.logK ? x.logK < y.logK : x.nterms < y.nterms;
     });
-    long off = 0, wg = 0, boff = 0;
+    long off = 0, boff = 0;
     p->rt->poly_max_logk = 8;
     for (size_t i = 0; i < poly_rows.size(); ++i) {
       RowDesc& r = poly_rows[i];
@@ -1122,13 +1125,14 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       c.nrows++;
       c.ndeg = std::max(c.ndeg, r.nterms + 1);
     }
-    for (int i = 0; i < p->rt->poly_cls.n; ++i) {
+    for (int i = 0; i < p->rt->poly_cls.n; ++i) {         // per tile size (launch): classes in table order
       PolyClass& c = p->rt->poly_cls.c[i];
-      const long tb = 1L << (POLY_LOGP - c.logK);
+      const int tile = std::max(12, c.logK);                // log2 of the workgroup tile
+      const long tb = 1L << (tile - c.logK);
+      long& wg = p->rt->poly_wgs[tile - 12];
       c.wg_first = int(wg);
       wg += (long(c.nrows) * c.ndeg + tb - 1) / tb;
     }
-    p->rt->poly_wgs = wg;
     p->rt->poly_coef_elems = off;
     p->rt->poly_band_elems = boff;
     p->rt->table.insert(p->rt->table.end(), poly_rows.begin(), poly_rows.end());
@@ -1492,7 +1496,8 @@ int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols
 template <typename T>
 int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   int rc = CWT_OK;
-  for (int g = 1; g >= 0 && !rc; --g) {       // the default tile's rows first (the longer launch), then the half-size tiles
+  for (int g = 0; g < 2 && !rc; ++g) {        // the half-size tiles first (by far the longer launch since the rows with long
+                                              // halos went to the polynomial form), then the default tile's rows
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows) continue;
     switch (G.logp) {
@@ -1553,14 +1558,16 @@ int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int6
   }
 }
 
-// Band-limited rows in polynomial form: interval coefficients (k_poly_coef), then the streaming kernel (k_poly_rows).
+// Band-limited rows in polynomial form: the filtered bands and the interval coefficients (k_poly_band, k_poly_coef) ...
+// st2 != nullptr: the 8192- and 4096-point tiles on that second stream beside the 16384-point ones (three independent,
+// latency-bound launches of one round of workgroups each: 30 + 19 + 20 us back to back), joined into st again.
 template <typename T>
-int launch_poly(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, hipStream_t st, hipStream_t st2 = nullptr) {
   const cwt_plan::RowTable* rt = p->rt;
   int rc = grow(&p->pcoef, &p->pcoef_bytes, size_t(rt->poly_coef_elems) * sizeof(cplx<T>), st);
   if (!rc) rc = grow(&p->pband, &p->pband_bytes, size_t(rt->poly_band_elems) * sizeof(cplx<T>), st);
   if (rc) return rc;
-  static const bool once = (allow_big_lds(&k_poly_coef<T>), true);
+  static const bool once = (allow_big_lds(&k_poly_coef<T, 13>), allow_big_lds(&k_poly_coef<T, 14>), true);
   (void)once;
   const RowDesc* rows = rt->rows_dev + rt->poly_first;
   cplx<T>* coef = static_cast<cplx<T>*>(p->pcoef);
@@ -1571,20 +1578,43 @@ int launch_poly(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, cplx<T>* W, 
                          xhat, rows + r0, mo, twn_of<T>(p), p->logN, band);
   }, st);
   if (rc) return rc;
-  rc = timed_launch(p, KC_POLY_COEF, [&] {
-    hipLaunchKernelGGL((k_poly_coef<T>), dim3(unsigned(rt->poly_wgs)), dim3(1 << (POLY_LOGP - 4)),
-                       ((size_t(1) << POLY_LOGP) + (size_t(1) << (POLY_LOGP - 4))) * sizeof(T), st,
-                       static_cast<const cplx<T>*>(band), rows, static_cast<const cplx<T>*>(p->tw_all), rt->poly_cls, coef);
-  }, st);
-  if (rc) return rc;
+  // largest tiles first: the 16384-point workgroups take a whole CU each and should find the chip as empty as it gets
+  const cplx<T>* tw = static_cast<const cplx<T>*>(p->tw_all);
+  auto lds_of = [](int lp) { return ((size_t(1) << lp) + (size_t(1) << (lp - 4))) * sizeof(T); };
+  const bool split = st2 && rt->poly_wgs[2] && (rt->poly_wgs[1] || rt->poly_wgs[0]);
+  hipStream_t s2 = split ? st2 : st;
+  if (split) {
+    HIPCHECK(hipEventRecord(p->ev_big, st));             // the bands are ready
+    HIPCHECK(hipStreamWaitEvent(st2, p->ev_big, 0));
+  }
+  if (!rc && rt->poly_wgs[2]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 14>), dim3(unsigned(rt->poly_wgs[2])), dim3(1024), lds_of(14), st,
+                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, st);
+  if (!rc && rt->poly_wgs[1]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 13>), dim3(unsigned(rt->poly_wgs[1])), dim3(512), lds_of(13), s2,
+                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, s2);
+  if (!rc && rt->poly_wgs[0]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 12>), dim3(unsigned(rt->poly_wgs[0])), dim3(256), lds_of(12), s2,
+                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, s2);
+  if (!rc && split) {
+    HIPCHECK(hipEventRecord(p->ev_big, st2));
+    HIPCHECK(hipStreamWaitEvent(st, p->ev_big, 0));
+  }
+  return rc;
+}
+// ... then the streaming kernel (k_poly_rows)
+template <typename T>
+int launch_poly_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  const cwt_plan::RowTable* rt = p->rt;
+  const RowDesc* rows = rt->rows_dev + rt->poly_first;
+  const cplx<T>* coef = static_cast<const cplx<T>*>(p->pcoef);
   const int64_t per_wg = 256 * (sizeof(T) == 8 ? 1 : 2) * POLY_PASSES;
   // LDS: the coefficient sets of the intervals one workgroup touches (shortest interval 2^POLY_MIN_LOGR samples)
   const size_t lds2 = size_t((per_wg >> POLY_MIN_LOGR) + 2) * (POLY_MAX_DEGREE + 1) * sizeof(cplx<T>);
   return timed_launch(p, KC_POLY, [&] {
     for (int r0 = 0; r0 < rt->n_poly; r0 += kMaxGridY)
       hipLaunchKernelGGL((k_poly_rows<T>), dim3(unsigned((ncols + per_wg - 1) / per_wg), std::min(kMaxGridY, rt->n_poly - r0)),
-                         dim3(256), lds2, st, rows + r0, static_cast<const cplx<T>*>(coef), twn_of<T>(p), p->logN, W,
-                         long(ldw), long(ncols));
+                         dim3(256), lds2, st, rows + r0, coef, twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
   }, st);
 }
 
@@ -1666,6 +1696,23 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
+  // Polynomial rows, first half: bands + interval coefficients.  Short, latency-bound launches of LARGE workgroups (a
+  // 16384-point transform fills a CU) on which the biggest kernel of the step (k_poly_rows) waits: they go first, and the
+  // overlap-save rows -- thousands of workgroups that need nothing but the signal and would otherwise flood every CU before
+  // these get a slot (measured: k_poly_coef 337 us instead of 67, k_poly_rows alone at the end of the step) -- are queued
+  // behind them.  Then the HBM-bound k_poly_rows and the VALU-bound overlap-save rows share the CUs.
+  const bool poly_on_side = p->rt->n_poly && side_narrow;
+  if (p->rt->n_poly) {
+    rc = launch_poly_coef<T>(p, xhat, mo, poly_on_side ? p->side[0] : p->stream, poly_on_side ? p->side2 : nullptr);
+    if (rc) return rc;
+    if (poly_on_side) HIPCHECK(hipEventRecord(p->ev_coef, p->side[0]));
+  }
+  if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
+    if (poly_on_side) HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_coef, 0));
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1]);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
+  }
   if (p->rt->n_wide) {                 // two-pass rows, chunk by chunk on the plan's stream (one intermediate buffer)
     const int logK = two_pass_logk(p), logR = logN - logK;
     const int chunk = balanced_chunk(p, p->rt->n_wide);
@@ -1706,9 +1753,9 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   // band-limited rows: on a side stream beside the two-pass chain (fills its kernel boundaries and
   // tails) when "overlap_narrow" is set, else on the plan's own stream
   bool narrow_on_side = false;
-  if (p->rt->n_poly) {                 // on the side stream of the band-limited rows (joined below), else on the plan's
-    narrow_on_side = side_narrow;
-    rc = launch_poly<T>(p, xhat, mo, W, ldw, ncols, narrow_on_side ? p->side[0] : p->stream);
+  if (p->rt->n_poly) {                 // second half, on the same stream as the first (joined below when that is a side stream)
+    narrow_on_side = poly_on_side;
+    rc = launch_poly_rows<T>(p, W, ldw, ncols, poly_on_side ? p->side[0] : p->stream);
     if (rc) return rc;
     if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
   }
@@ -1887,6 +1934,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  if (!rc && hipEventCreate(&p->ev_coef) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
   p->narrow_mix = precision == 64;
@@ -1922,6 +1970,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
+  if (p->ev_coef) (void)hipEventDestroy(p->ev_coef);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1986,6 +2035,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
+  else if (k == "poly_max_logk") { if (value < 8 || value > 14) return fail(CWT_EINVAL, "poly_max_logk in [8, 14]"); p->poly_max_logk = int(value); }
   else if (k == "poly_min_logn") { if (value < 14 || value > 24) return fail(CWT_EINVAL, "poly_min_logn in [14, 24]"); p->poly_min_logn = int(value); }
   else if (k == "aols_min_rows") { if (value < 1 || value > 65536) return fail(CWT_EINVAL, "aols_min_rows >= 1"); p->aols_min_rows = int(value); }
   else if (k == "ols_side") p->ols_side = value != 0;
@@ -2236,10 +2286,9 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
-  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);
-  if (!rc) rc = launch_ols_rows<T>(p, static_cast<cplx<T>*>(W_dev), ldw, ncols, p->side[1]);
-  if (rc) return rc;
-  HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
+  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
+  if (rc) return rc;                                    // polynomial rows)
+  (void)W_dev; (void)ldw; (void)ncols;
   p->ols_launched = 1;
   return CWT_OK;
 }

@@ -1291,16 +1291,20 @@ k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, co
 // The host picks K' and D per row: D is the smallest even degree with  F(kappa)/F_max * |theta|^(D+1)/(D+1)! <= the support
 // threshold on every bin, i.e. the truncation is treated like the band limit itself.
 constexpr int POLY_MAX_CLASSES = 8;       // K' = 2^8 ... 2^14 + one spare
-constexpr int POLY_LOGP = 14;             // points per workgroup of k_poly_coef (1024 threads)
+constexpr int POLY_LOGP = 14;             // largest K' = points per workgroup of the largest k_poly_coef tile (1024 threads)
 constexpr int POLY_MAX_DEGREE = 24;
-constexpr int POLY_PASSES = 2;            // passes of 256 lanes x 16 bytes per workgroup of k_poly_rows
+#ifndef CWT_POLY_PASSES
+#define CWT_POLY_PASSES 2
+#endif
+constexpr int POLY_PASSES = CWT_POLY_PASSES;   // passes of 256 lanes x 16 bytes per workgroup of k_poly_rows (measured: 1, 3, 4 slower)
 constexpr int POLY_MIN_LOGR = 6;          // shortest interval: 64 samples
 struct PolyClass {
   int logK;        // log2 K'
   int row_first;   // first row of the class in the row table handed to the kernels
   int nrows;
   int ndeg;        // degrees computed per row of this class = 1 + the largest degree in it
-  int wg_first;    // first workgroup of the class in the k_poly_coef launch
+  int wg_first;    // first workgroup of the class in ITS k_poly_coef launch (one launch per tile size: 4096-point tiles for
+                   // K' <= 4096, 8192 for K' = 8192, 16384 for K' = 16384)
 };
 struct PolyClasses {
   PolyClass c[POLY_MAX_CLASSES];
@@ -1337,14 +1341,16 @@ k_poly_band(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
   yb[rd.aux_off + q] = cmul<T>(y, ph);
 }
 
-// One workgroup = 2^(14 - LOGK) transforms of K' = 2^LOGK points, ROWS layout (lanes run along the interval index m, so the
+// One workgroup = 2^(LOGP - LOGK) transforms of K' = 2^LOGK points, ROWS layout (lanes run along the interval index m, so the
 // planes are written in whole lines; K' <= 1024: a transform lives in one wavefront and needs no workgroup barrier).
 // Transform `job` of the class = (row, degree): job = row * ndeg + d; its input is the row's band times (i theta)^d / d!.
-template <typename T, int LOGK>
+// Tiles of 4096 points (256 threads, four workgroups per CU) wherever K' allows: these launches sit on the critical path of the
+// step (k_poly_rows waits for them) and are latency bound -- one 16384-point workgroup per CU for everything measured 67 us.
+template <typename T, int LOGK, int LOGP>
 __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows,
                                                const cplx<T>* __restrict__ tw_all, const PolyClass& pc,
                                                unsigned local_wg, cplx<T>* __restrict__ coef, T* lds) {
-  constexpr int LOGTB = POLY_LOGP - LOGK, TB = 1 << LOGTB, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
+  constexpr int LOGTB = LOGP - LOGK, TB = 1 << LOGTB, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
   using F = ct::Fft<T, LOGK, LOGTB, false>;
   F f;
   f.j = threadIdx.x & (NT - 1);
@@ -1387,19 +1393,23 @@ __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, c
   for (int e = 0; e < 16; ++e) out[e * NT] = mk<T>(re[e], im[e]);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(1 << (POLY_LOGP - 4), 4)
+template <typename T, int LOGP>
+__global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ tw_all,
             PolyClasses cls, cplx<T>* __restrict__ coef) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
+  // the classes of this launch: log2 K' in (LOGP - 1, LOGP] for the two large tiles, <= 12 for the 4096-point tile
+  constexpr int LK_LO = LOGP == 12 ? 8 : LOGP, LK_HI = LOGP;
   PolyClass pc = cls.c[0];
+  bool found = false;
 #pragma unroll
-  for (int i = 1; i < POLY_MAX_CLASSES; ++i)
-    if (i < cls.n && int(blockIdx.x) >= cls.c[i].wg_first) pc = cls.c[i];
+  for (int i = 0; i < POLY_MAX_CLASSES; ++i)
+    if (i < cls.n && cls.c[i].logK >= LK_LO && cls.c[i].logK <= LK_HI && int(blockIdx.x) >= cls.c[i].wg_first) { pc = cls.c[i]; found = true; }
+  if (!found) return;
   const unsigned local = blockIdx.x - unsigned(pc.wg_first);
 #define CWT_POLY_CASE(LK) \
-  case LK: poly_coef_body<T, LK>(yb, rows, tw_all, pc, local, coef, lds); break;
+  case LK: if constexpr (LK >= LK_LO && LK <= LK_HI) poly_coef_body<T, LK, LOGP>(yb, rows, tw_all, pc, local, coef, lds); break;
   switch (pc.logK) {
     CWT_POLY_CASE(8) CWT_POLY_CASE(9) CWT_POLY_CASE(10) CWT_POLY_CASE(11) CWT_POLY_CASE(12) CWT_POLY_CASE(13)
     CWT_POLY_CASE(14)
