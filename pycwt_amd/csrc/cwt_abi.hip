@@ -194,6 +194,8 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
+  int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
+                           // HIP graph on its second occurrence and replay it from the third on
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
@@ -280,6 +282,7 @@ struct cwt_plan {
     RowDesc* rows_pinned = nullptr;
     hipEvent_t uploaded = nullptr;
     uint64_t used = 0;
+    uint64_t build_id = 0;               // changes whenever the table is rebuilt (graphs captured over it are stale then)
   };
   RowTable slots[2];
   RowTable* rt = &slots[0];
@@ -293,6 +296,10 @@ struct cwt_plan {
   void* bs_a = nullptr; size_t bs_a_bytes = 0;          // chirp-premultiplied rows, slab x n0
   void* bs_spec = nullptr; size_t bs_spec_bytes = 0;    // their spectra, slab x M
   void* bs_par = nullptr; size_t bs_par_bytes = 0;      // per-row a, amp_re, amp_im (doubles)
+  // HIP graphs of repeated cwt_transform calls (option "graph"): key = the call's buffers + the row table's identity
+  struct GraphSlot { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; int seen = 0; uint64_t used = 0; };
+  GraphSlot graphs[4];
+  uint64_t graph_replays = 0;
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
@@ -1973,6 +1980,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_coef) (void)hipEventDestroy(p->ev_coef);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
+  for (auto& g : p->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
   void* bufs[] = {p->tw_all, p->twn_lo, p->weights_dev, p->Z, p->xs, p->xm, p->xsa, p->pcoef, p->pband, p->range_dev, p->hx, p->hxhat, p->hW,
@@ -2032,6 +2040,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "pass_a_small") p->pass_a_small = value != 0;
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
   else if (k == "ols") p->ols = value != 0;
+  else if (k == "graph") p->graph = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
@@ -2175,6 +2184,7 @@ int upload_row_table(cwt_plan* p, const std::vector<double>& key) {
                           p->stream));
   HIPCHECK(hipEventRecord(t->uploaded, p->stream));
   t->key = key;
+  t->build_id = ++p->tick;
   return CWT_OK;
 }
 
@@ -2309,29 +2319,75 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   HIPCHECK(hipSetDevice(p->device));
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
-  if (!xhat_dev) {   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
-    if (p->rt->n_ols == nrows) {                          // every row is an overlap-save row on the real signal
-      const Mother mo = mother_of(mother, param);
-      return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
-                           : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
-    }
+  // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
+  const bool only_ols = !xhat_dev && p->rt->n_ols == nrows;      // every row is an overlap-save row on the real signal
+  if (!xhat_dev && !only_ols) {
     rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * 2 * p->esize(), p->stream);
     if (rc) return rc;
     xhat_dev = p->hxhat;
   }
   const Mother mo = mother_of(mother, param);
-  p->ols_launched = 0;
-  if (p->rt->n_ols && p->ols_early && !p->profile) {
-    rc = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
-                       : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
-    if (rc) return rc;
-  }
-  rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
-                     : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
-  if (!rc) rc = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
+  auto enqueue = [&]() -> int {
+    p->ols_launched = 0;
+    int r = CWT_OK;
+    if (only_ols)
+      return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
+                           : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
+    if (p->rt->n_ols && p->ols_early && !p->profile) {
+      r = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
+                        : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
+      if (r) return r;
+    }
+    r = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
+                      : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
+    if (!r) r = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                               : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
-  p->ols_launched = 0;
-  return rc;
+    p->ols_launched = 0;
+    return r;
+  };
+  if (!p->graph || p->profile) return enqueue();
+  // Option "graph": the same call (buffers, shapes, row table) for the second time is captured into a HIP graph -- the side
+  // streams join the capture through the events that fork and join them -- and replayed from then on: one launch instead
+  // of 10-20 launches and as many event operations per transform.
+  const std::vector<uint64_t> gkey = {uint64_t(reinterpret_cast<uintptr_t>(x_dev)), uint64_t(n0),
+                                      uint64_t(reinterpret_cast<uintptr_t>(xhat_dev)), uint64_t(reinterpret_cast<uintptr_t>(W_dev)),
+                                      uint64_t(ldw), uint64_t(ncols), uint64_t(reinterpret_cast<uintptr_t>(p->rt)), p->rt->build_id,
+                                      uint64_t(reinterpret_cast<uintptr_t>(p->stream))};
+  cwt_plan::GraphSlot* slot = nullptr;
+  for (auto& g : p->graphs) if (g.key == gkey) slot = &g;
+  if (slot && slot->exec) {
+    slot->used = ++p->tick;
+    ++p->graph_replays;
+    HIPCHECK(hipGraphLaunch(slot->exec, p->stream));
+    return CWT_OK;
+  }
+  if (!slot) {                                            // first occurrence: remember it (least recently used slot), run plainly
+    slot = &p->graphs[0];
+    for (auto& g : p->graphs) if (g.used < slot->used) slot = &g;
+    if (slot->exec) { HIPCHECK(hipStreamSynchronize(p->stream)); (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+    slot->key = gkey; slot->seen = 1; slot->used = ++p->tick;
+    return enqueue();
+  }
+  slot->used = ++p->tick;                                 // second occurrence: every buffer has its size, nothing allocates
+  if (hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    p->graph = 0;                                         // no capture on this runtime: plain launches from now on
+    return enqueue();
+  }
+  rc = enqueue();
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(p->stream, &graph);
+  if (rc || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    p->graph = 0;
+    return rc ? rc : enqueue();
+  }
+  const hipError_t ei = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) { slot->exec = nullptr; (void)hipGetLastError(); p->graph = 0; return enqueue(); }
+  HIPCHECK(hipGraphLaunch(slot->exec, p->stream));
+  return CWT_OK;
 }
 
 int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int64_t xhat_ld, int mother,
@@ -2894,9 +2950,9 @@ namespace {
 // overlap-save classes the block spectra of that tile size) + a per-row part.  Fitted to the per-class launch durations of
 // bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt.
 struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term,
-                   aols_fixed, aols_row, poly_fixed, poly_row; };
-constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.4, 8.0, 2.85, 0.9, 40.0, 4.0, 20.0, 2.6};
-constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55, 35.0, 2.3, 18.0, 1.4};
+                   aols_fixed, aols_row, poly_fixed, poly_row, poly_coef; };
+constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.5, 8.0, 2.85, 0.9, 45.0, 3.8, 25.0, 2.7, 2.2};
+constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55, 40.0, 2.3, 22.0, 1.4, 1.1};
 
 // Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
 // length / 2^20: per-row parts scale with it, per-launch parts do not; chunk = rows per two-pass launch pair.
@@ -2910,7 +2966,13 @@ double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double n
     else if (kind == 2) { if (!seen_big) { seen_big = true; total += c.k2048_fixed; } total += c.k2048_row * nscale; }
     else if (kind == 4) { if (!seen_ols) { seen_ols = true; total += c.ols_fixed; } total += c.ols_row * nscale; }
     else if (kind == 5) { if (!seen_olsh) { seen_olsh = true; total += c.olsh_fixed; } total += c.olsh_row * nscale; }
-    else if (kind == 7) { if (!seen_poly) { seen_poly = true; total += c.poly_fixed; } total += c.poly_row * nscale * (1.0 + 0.015 * std::max(0, terms - 8)); }
+    else if (kind == 7) {
+      // stage 2 per row (a little more per degree) + the row's share of stage 1: (D + 1) K' coefficients, priced at the
+      // measured 2.2 us (fp64) of a K' = 16384, D = 8 row (profiles/r04_shards.txt)
+      if (!seen_poly) { seen_poly = true; total += c.poly_fixed; }
+      total += c.poly_row * nscale * (1.0 + 0.015 * std::max(0, terms - 8));
+      total += c.poly_coef * double((terms + 1) << logk) / double(9 << 14);
+    }
     else if (kind == 6) { if (!seen_aols) { seen_aols = true; total += c.aols_fixed * std::max(nscale, 0.5); } total += c.aols_row * nscale; }
     else {
       if (!seen_nar) { seen_nar = true; total += c.nar_fixed; }

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 OUT=$PWD/gpurun_out/$tag
 mkdir -p $OUT
-BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-live-traffic $*"
 SER="$BENCH --opt overlap_narrow=0 --opt ols_early=0 --opt ols_side=0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o cwt -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ser -o cwt -- $SER > $OUT/trace_ser.log 2>&1

@@ -23,25 +23,12 @@ def short(name):
     return name.replace("void cwt::", "").replace("cwt::", "")[:60]
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_class          # noqa: E402  (one mapping of kernel names to classes for bench.py and this summary)
+
+
 def klass(name):
-    if name.startswith("k_narrow_ct_big"):
-        return "narrow_big"
-    if name.startswith("k_narrow_ct_many"):
-        return "narrow_many"
-    if name.startswith("k_ols_fwd"):
-        return "ols_fwd"
-    if name.startswith("k_ols_ct"):
-        return "ols_small" if name.rstrip(">").endswith(", 12") else "ols"     # half-size tiles (4096 points)
-    for k in ("k_narrow", "k_pass_a", "k_pass_b", "k_small", "k_direct", "k_icwt"):
-        if name.startswith(k):
-            args = name[name.find("<") + 1:name.rfind(">")].split(", ") if "<" in name else []
-            fwd = False
-            if name.startswith("k_pass_b_ct") and len(args) >= 4:
-                fwd = args[3] == "true"                       # CONJ: the forward FFT of the signal
-            elif name.startswith("k_pass_a_ct<") and args:
-                fwd = args[-1] in ("1", "2")                  # MODE IN_REAL / IN_CPLX
-            return ("fwd_" if fwd else "") + k[2:]
-    return None
+    return kernel_class(name)
 
 
 stats = {}
