@@ -236,6 +236,7 @@ struct cwt_plan {
   void* xsa = nullptr;      // its block spectra (nblocks x (P + 8) complex)
   size_t xsa_bytes = 0;
   // buffers of cwt_execute_host
+  void* hstage = nullptr; size_t hstage_bytes = 0;   // page-locked staging of its small calls (signal in, W and spectrum out)
   void* hx = nullptr; size_t hx_bytes = 0;
   void* hxhat = nullptr; size_t hxhat_bytes = 0;
   void* hW = nullptr; size_t hW_bytes = 0;
@@ -1993,6 +1994,7 @@ int cwt_plan_destroy(cwt_plan* p) {
     if (t.rows_pinned) (void)hipHostFree(t.rows_pinned);
     if (t.uploaded) (void)hipEventDestroy(t.uploaded);
   }
+  if (p->hstage) (void)hipHostFree(p->hstage);
   for (int i = 0; i < 2; ++i) {
     if (p->weights_pinned[i]) (void)hipHostFree(p->weights_pinned[i]);
     if (p->weights_ev[i]) (void)hipEventDestroy(p->weights_ev[i]);
@@ -2853,7 +2855,24 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!rc) rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * 2 * es, p->stream);
   if (!rc && W_host) rc = grow(&p->hW, &p->hW_bytes, size_t(nrows) * size_t(n0) * 2 * es, p->stream);
   if (rc) return rc;
-  HIPCHECK(hipMemcpyAsync(p->hx, x_host, size_t(n0) * es, hipMemcpyHostToDevice, p->stream));
+  // Small calls (the reference's canonical 504-point series: 4 KB in, 0.7 MB out) are all latency: a copy to or from pageable
+  // memory makes the runtime stage and synchronise on its own, once per copy.  They go through ONE page-locked buffer of the
+  // plan instead -- memcpy in, three asynchronous copies, one synchronisation, memcpy out.
+  const size_t in_b = size_t(n0) * es, xh_b = xhat_host ? size_t(p->N) * 2 * es : 0;
+  const size_t w_b = W_host ? size_t(nrows) * size_t(n0) * 2 * es : 0;
+  const bool staged = in_b + xh_b + w_b <= (size_t(4) << 20);
+  char* stage = nullptr;
+  if (staged) {
+    if (p->hstage_bytes < (size_t(4) << 20)) {
+      if (hipHostMalloc(&p->hstage, size_t(4) << 20) != hipSuccess) return fail(CWT_ENOMEM, "pinned staging allocation failed");
+      p->hstage_bytes = size_t(4) << 20;
+    }
+    stage = static_cast<char*>(p->hstage);
+    std::memcpy(stage, x_host, in_b);
+    HIPCHECK(hipMemcpyAsync(p->hx, stage, in_b, hipMemcpyHostToDevice, p->stream));
+  } else {
+    HIPCHECK(hipMemcpyAsync(p->hx, x_host, in_b, hipMemcpyHostToDevice, p->stream));
+  }
   if (W_host && p->auto_target > 0 && p->logN <= p->loglmax) {
     // single-workgroup transforms compute every bin of every row anyway: round-off costs nothing, no need to look
     const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
@@ -2880,6 +2899,14 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);
   else rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
   if (rc) return rc;
+  if (staged) {
+    if (xh_b) HIPCHECK(hipMemcpyAsync(stage + in_b, p->hxhat, xh_b, hipMemcpyDeviceToHost, p->stream));
+    if (w_b) HIPCHECK(hipMemcpyAsync(stage + in_b + xh_b, p->hW, w_b, hipMemcpyDeviceToHost, p->stream));
+    HIPCHECK(hipStreamSynchronize(p->stream));
+    if (xh_b) std::memcpy(xhat_host, stage + in_b, xh_b);
+    if (w_b) std::memcpy(W_host, stage + in_b + xh_b, w_b);
+    return CWT_OK;
+  }
   if (xhat_host)
     HIPCHECK(hipMemcpyAsync(xhat_host, p->hxhat, size_t(p->N) * 2 * es, hipMemcpyDeviceToHost, p->stream));
   if (W_host) return copy_d2h(p, W_host, p->hW, size_t(nrows) * size_t(n0) * 2 * es);

@@ -8,10 +8,11 @@ import sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(f"""# Per row class of the bench workloads (python bench.py, default command; N = 2^20, 256 scales; HIP events in the
 # profiling pass of bench.py, every kernel alone; `roofline.per_class` of {sys.argv[1]}).
-# frac = rows x N x sizeof(complex) / time / 8 TB/s; traffic = PMC bytes (FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic_<config>.json) /
-# algorithmic bytes -- WRITE_SIZE is uncalibrated on gfx950 (it reads 1.13x the exact output bytes of the band-limited kernel in fp64
-# and 0.56x in fp32), so the ratios compare classes and variants, not absolutes.""")
-blocks = [(d["config"]["workload"], d)] + [(v["workload"], v) for v in d.get("extra", {}).values()]
+# frac = rows x N x sizeof(complex) / time / 8 TB/s; traffic = PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) / algorithmic bytes.  Config 2:
+# measured inside the bench run (bench.py live_traffic: two rocprofv3 child passes) and calibrated on k_poly_rows (exact output
+# bytes) and k_icwt (exact input bytes) -- both factors came out as 1.0000; config 3: profiles/traffic_<config>.json (the same
+# passes run by tools/gpu_profile.sh in the same session).""")
+blocks = [(d["config"]["workload"], d)] + [(v["workload"], v) for v in d.get("extra", {}).values() if "roofline" in v and "per_class" in v.get("roofline", {})]
 for name, b in blocks:
     r = b["roofline"]
     fi = b.get("from_idle", {})
@@ -29,3 +30,11 @@ for name, b in blocks:
         print(f"{k:14s} {'':5s} {ms * 1e3:9.1f}")
         tot += ms
     print(f"{'sum of kernels':14s} {'':5s} {tot * 1e3:9.1f}")
+
+for k, v in d.get("extra", {}).items():
+    if not ("roofline" in v and "per_class" in v.get("roofline", {})):
+        print(f"\n== extra.{k}: " + ", ".join(f"{a} = {b:.4g}" if isinstance(b, float) else f"{a} = {b}" for a, b in v.items()
+                                                if not isinstance(b, (dict, list)) and a not in ("workload", "includes", "parity_all_rows")))
+        print("   " + str(v.get("workload", "")))
+if "icwt" in d:
+    print("\n== icwt (standalone pass over the device-resident W of config 2): " + ", ".join(f"{a} = {b:.4g}" if isinstance(b, float) else f"{a} = {b}" for a, b in d["icwt"].items()))
