@@ -194,6 +194,7 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
+  int ols_hold = 0;        // 1 = the overlap-save rows wait for the coefficients of the polynomial rows (tuning; see rows_launch)
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
                            // HIP graph on its second occurrence and replay it from the third on
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
@@ -1705,10 +1706,11 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
   // Polynomial rows, first half: bands + interval coefficients.  Short, latency-bound launches of LARGE workgroups (a
-  // 16384-point transform fills a CU) on which the biggest kernel of the step (k_poly_rows) waits: they go first, and the
-  // overlap-save rows -- thousands of workgroups that need nothing but the signal and would otherwise flood every CU before
-  // these get a slot (measured: k_poly_coef 337 us instead of 67, k_poly_rows alone at the end of the step) -- are queued
-  // behind them.  Then the HBM-bound k_poly_rows and the VALU-bound overlap-save rows share the CUs.
+  // 16384-point transform fills a CU) on which the biggest kernel of the step (k_poly_rows) waits: they are queued before
+  // the overlap-save rows.  What starved them in the first build (k_poly_coef 337 us instead of 67, k_poly_rows alone at
+  // the end of the step) were the 512-thread / 68-KB workgroups of the 8192-point overlap-save tiles launched first; with
+  // the 4096-point tiles first the coefficient workgroups find their slots, and holding the overlap-save rows back until
+  // the coefficients are done (option "ols_hold") only leaves the chip idle: 0.916 against 0.898 ms at config 2.
   const bool poly_on_side = p->rt->n_poly && side_narrow;
   if (p->rt->n_poly) {
     rc = launch_poly_coef<T>(p, xhat, mo, poly_on_side ? p->side[0] : p->stream, poly_on_side ? p->side2 : nullptr);
@@ -1716,7 +1718,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     if (poly_on_side) HIPCHECK(hipEventRecord(p->ev_coef, p->side[0]));
   }
   if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
-    if (poly_on_side) HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_coef, 0));
+    if (poly_on_side && p->ols_hold) HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_coef, 0));
     rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1]);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
@@ -1877,8 +1879,11 @@ int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
 // the default priority: all four queues are served alike.  Rounds 1-2 created them at the lowest priority (filler work
 // under the two-pass chain); at sustained clocks that measured +1 % on the fp64 step (1.005-1.007 against 0.993-0.998 ms,
 // three pairs) and +-0 in fp32.  CWT_SIDE_PRIORITY=low restores it (tuning).
-hipError_t create_side_stream(hipStream_t* s) {
+hipError_t create_side_stream(hipStream_t* s, bool poly = false) {
   int least = 0, greatest = 0;
+  const char* ep = std::getenv("CWT_POLY_PRIORITY");
+  if (poly && ep && std::string(ep) == "high" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
   const char* e = std::getenv("CWT_SIDE_PRIORITY");
   if (e && std::string(e) == "low" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
@@ -1936,14 +1941,14 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
-    if (create_side_stream(&p->side[i]) != hipSuccess ||
+    if (create_side_stream(&p->side[i], i == 0) != hipSuccess ||
         hipEventCreate(&p->ev_a[i]) != hipSuccess || hipEventCreate(&p->ev_b[i]) != hipSuccess)
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipEventCreate(&p->ev_coef) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
+  if (!rc && (create_side_stream(&p->side2, true) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
@@ -2043,6 +2048,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
   else if (k == "ols") p->ols = value != 0;
   else if (k == "graph") p->graph = value != 0;
+  else if (k == "ols_hold") p->ols_hold = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
