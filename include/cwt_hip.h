@@ -107,6 +107,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
+ *   "fuse_small"   0 = transforms that fit one workgroup launch the forward FFT and the rows separately (default 1: one
+ *                  launch, k_small_signal; cwt_transform and cwt_execute_host)
+ *   "host_direct"  0 = cwt_execute_host stages such transforms through device buffers and copy operations (default 1: the
+ *                  kernel reads and writes page-locked host memory itself)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
@@ -145,6 +149,11 @@ int cwt_malloc(int device, void** ptr_dev, size_t bytes);
 int cwt_free(int device, void* ptr_dev);
 int cwt_memcpy_h2d(cwt_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
 int cwt_memcpy_d2h(cwt_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+/* Page-locked host memory (ordinary memory to the host; the GPU reads and writes it over PCIe).  A W_host of
+ * cwt_execute_host that lies in such a buffer is written by the kernels themselves when the transform fits one
+ * workgroup -- no staging copy: that copy is a third of what the reference's canonical 504-point call costs here.   */
+int cwt_host_malloc(void** ptr_host, size_t bytes);
+int cwt_host_free(void* ptr_host);
 
 /* ---- hot path, device resident -----------------------------------------
  * Forward transform of the real signal, zero padded at the end to nfft:
@@ -294,7 +303,9 @@ int cwt_coherence_histogram(cwt_plan* plan, const void* r2_dev, int64_t ld, int 
 /* ---- host convenience: what the ctypes shim of pycwt.cwt() calls ---------
  * x_host: n0 reals of the plan's precision.  W_host: nrows x n0 complex (may be
  * NULL).  xhat_host: nfft complex (may be NULL) for the 5th return value
- * (wavelet.py:123-124).  Synchronous.                                        */
+ * (wavelet.py:123-124).  Synchronous.  Transforms that fit one workgroup
+ * (nfft <= 4096) run as ONE kernel that reads the signal and writes the spectrum
+ * and W through page-locked host memory (options "fuse_small", "host_direct").  */
 int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother, double param,
                      double dt, const double* scales_host, int nrows, void* W_host,
                      void* xhat_host);

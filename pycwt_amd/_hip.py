@@ -34,6 +34,8 @@ SYMBOLS = [
     ("cwt_free", C.c_int, [C.c_int, _P]),
     ("cwt_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("cwt_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("cwt_host_malloc", C.c_int, [C.POINTER(_P), C.c_size_t]),
+    ("cwt_host_free", C.c_int, [_P]),
     ("cwt_forward_fft", C.c_int, [_P, _P, C.c_int64, _P]),
     ("cwt_transform_rows", C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.c_int, _P, C.c_int64, C.c_int64]),
@@ -102,6 +104,7 @@ class Library:
             fn.restype = restype
             fn.argtypes = argtypes
             setattr(self, name, fn)
+        self.pinned = PinnedPool(self)
 
     def backend(self) -> str:
         return self.cwt_backend().decode()
@@ -114,6 +117,65 @@ class Library:
         n = C.c_int(0)
         self.check(self.cwt_device_count(C.byref(n)))
         return n.value
+
+
+class _PinnedSlot:
+    """Returns a page-locked buffer to its pool when the last array (or view) on it is gone."""
+    __slots__ = ("pool", "ptr", "size")
+
+    def __init__(self, pool, ptr, size):
+        self.pool, self.ptr, self.size = pool, ptr, size
+
+    def __del__(self):
+        try:
+            self.pool._release(self.ptr, self.size)
+        except Exception:           # interpreter shutdown: the process is going away with its mappings
+            pass
+
+
+class PinnedPool:
+    """NumPy result arrays in page-locked host memory (cwt_host_malloc).  To the caller they are ordinary arrays; to
+    cwt_execute_host they are buffers the kernels of a short transform write over PCIe themselves, which removes the
+    staging copy of W -- 25 of the ~85 us of the reference's canonical 504-point call.  Buffers go back to the pool when
+    the array and every view of it are garbage; at most LIMIT bytes are ever pinned, then (or for results above ONE)
+    `empty` returns None and the caller uses pageable memory."""
+    LIMIT = 256 << 20
+    ONE = 4 << 20
+    GRAIN = 1 << 16
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.free = {}
+        self.total = 0
+        self.lock = threading.Lock()
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes == 0 or nbytes > self.ONE:
+            return None
+        size = (nbytes + self.GRAIN - 1) & ~(self.GRAIN - 1)
+        with self.lock:
+            stack = self.free.get(size)
+            ptr = stack.pop() if stack else None
+            if ptr is None:
+                if self.total + size > self.LIMIT:
+                    return None
+                self.total += size
+        if ptr is None:
+            p = _P()
+            if self.lib.cwt_host_malloc(C.byref(p), size) != 0 or not p.value:
+                with self.lock:
+                    self.total -= size
+                return None
+            ptr = p.value
+        buf = (C.c_char * nbytes).from_address(ptr)
+        buf._slot = _PinnedSlot(self, ptr, size)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _release(self, ptr, size):
+        with self.lock:
+            self.free.setdefault(size, []).append(ptr)
 
 
 _default = None
@@ -354,11 +416,18 @@ class Plan:
         x = np.ascontiguousarray(x, dtype=self.real)
         s = np.ascontiguousarray(scales, dtype=np.float64)
         n0 = x.size
-        W = np.empty((s.size, n0), dtype=self.cplx) if want_W else None
+        W = None
+        if want_W:
+            if self.nfft <= 4096:       # one kernel writes W over PCIe: into page-locked memory when the pool has some
+                W = self.lib.pinned.empty((s.size, n0), self.cplx)
+            if W is None:
+                W = np.empty((s.size, n0), dtype=self.cplx)
         xhat = np.empty(self.nfft, dtype=self.cplx) if want_xhat else None
-        self.lib.check(self.lib.cwt_execute_host(
-            self.h, x.ctypes.data_as(_P), n0, mother, float(param), float(dt), _dptr(s), s.size,
-            W.ctypes.data_as(_P) if want_W else None, xhat.ctypes.data_as(_P) if want_xhat else None))
+        rc = self.lib.cwt_execute_host(
+            self.h, x.ctypes.data, n0, mother, param, dt, _dptr(s), s.size,
+            W.ctypes.data if want_W else None, xhat.ctypes.data if want_xhat else None)
+        if rc:
+            self.lib.check(rc)
         return W, xhat
 
     @_locked

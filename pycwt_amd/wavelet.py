@@ -135,10 +135,10 @@ def _transform(plan, x_host, xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr):
         plan.transform_rows(xh_ptr, kind, param, dt, sj, W_ptr, n0, n0)
 
 
-def _cwt_builtin(x, dt, sj, kind, param, N, precision, device):
+def _cwt_builtin(x, dt, sj, kind, param, N, precision, device, finite):
     """W (rows x n0) and the spectrum (N) for a built-in mother through the device-resident entry points."""
     plan = _plan(N, precision, device, sj.size)
-    if np.isfinite(x).all():
+    if finite:
         return plan.execute_host(x, kind, param, dt, sj)
     es = np.dtype(plan.real).itemsize
     n0 = x.size
@@ -200,6 +200,37 @@ def _nan_rows(mother, sj, N, dt):
     with np.errstate(all="ignore"):
         bad = np.isnan(np.asarray(mother.psi_ft(sj * w_min)))
     return bad
+
+
+_geometry_cache = {}
+
+
+def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
+    """Everything of a call that does not depend on the samples: (N, sj, freqs, coi, fftfreqs[1:N//2], NaN-row mask or
+    None).  The reference recomputes these per call (wavelet.py:75-94, :120-121); at its canonical 504-point call that is
+    half of what a call costs here, so built-in mothers on the default grid keep the last few results.  The arrays of a
+    cached entry are never handed out: `cwt` returns copies."""
+    key = None
+    if freqs is None and hasattr(mother, "device_id"):
+        try:
+            key = (type(mother), mother.device_id(), n0, dt, dj, s0, J, pad)
+            hit = _geometry_cache.get(key)
+            if hit is not None:
+                return hit
+        except TypeError:                                   # an unhashable argument (array-valued dt ...): no cache
+            key = None
+    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
+    N = _next_pow2(n0) if pad else n0
+    bad = _nan_rows(mother, sj, N, dt) if hasattr(mother, "device_id") else None
+    if bad is not None and not bad.any():
+        bad = None
+    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)              # wavelet.py:94
+    geo = (N, sj, freqs, _coi(mother, n0, dt), ftfreqs[1:N // 2] / (2 * np.pi), bad)
+    if key is not None:
+        if len(_geometry_cache) >= 64:
+            _geometry_cache.clear()
+        _geometry_cache[key] = geo
+    return geo
 
 
 def _cwt_with_host_filter_bank(x, dt, sj, mother, N, precision, device):
@@ -284,28 +315,26 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
         return (a[0] + 1j * b[0], a[1], a[2], a[3], fft5, a[5])
     in_dtype = getattr(signal, "dtype", None)
     n0 = len(signal)
-    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
-
-    N = _next_pow2(n0) if pad else n0
+    user_freqs = freqs is not None
+    N, sj, freqs, coi, fftfreqs, bad = _geometry(mother, n0, dt, dj, s0, J, freqs, pad)
     real = np.float64 if precision == 64 else np.float32
-    if N != _next_pow2(N):                                  # pad=False with a length that is not a power of two
-        bad = _nan_rows(mother, sj, N, dt)
-        if bad.any() and not bad.all():
+    if N & (N - 1):                                         # pad=False with a length that is not a power of two
+        if bad is not None and not bad.all():
             sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
         kind, param = _device_id(mother)
         W, xhat = _cwt_unpadded(np.ascontiguousarray(signal, dtype=real), dt, sj, kind, param, precision, device)
     elif hasattr(mother, "device_id"):
         x = np.asarray(signal, dtype=real)
-        bad = _nan_rows(mother, sj, N, dt)
+        finite = bool(np.isfinite(x).all())
         # wavelet.py:111-115 drops the rows that are NaN throughout -- unless EVERY row is, which is what a NaN / inf
         # sample does to the whole matrix (:91): then the reference keeps all rows, and so do we
-        if bad.any() and not bad.all() and np.isfinite(x).all():
+        if bad is not None and not bad.all() and finite:
             keep = ~bad
             sj = sj[keep]
             freqs = np.asarray(freqs)[keep]
         kind, param = mother.device_id()
-        W, xhat = _cwt_builtin(x, dt, sj, kind, param, N, precision, device)
-        if bad.all():
+        W, xhat = _cwt_builtin(x, dt, sj, kind, param, N, precision, device, finite)
+        if bad is not None and bad.all():
             # every row carries a NaN in its filter (Paul, all scales beyond the overflow of exp(-f)): the reference keeps
             # all rows then (wavelet.py:112) and every one of them is NaN throughout
             W = np.full(W.shape, complex(np.nan, np.nan), dtype=W.dtype)
@@ -319,12 +348,12 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
         W = W.astype(np.complex128)
         xhat = xhat.astype(np.complex128)
 
-    coi = _coi(mother, n0, dt)
-    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)                 # wavelet.py:94
     fft5 = xhat[1:N // 2] / N ** 0.5
     if in_dtype == np.float32:
         fft5 = fft5.astype(np.complex64)        # the reference's FFT of a float32 signal is complex64 (wavelet.py:91, :123-124)
-    return (W, sj, freqs, coi, fft5, ftfreqs[1:N // 2] / (2 * np.pi))
+    if not user_freqs:
+        freqs = np.array(freqs)                 # (cached grids stay private)
+    return (W, np.array(sj), freqs, np.array(coi), fft5, np.array(fftfreqs))
 
 
 class DeviceTransform:

@@ -1,0 +1,31 @@
+"""pycwt_amd.cwt() at the reference's canonical size (504 samples, default grid): the whole call, the C call inside it,
+and the Python around it (the C entry point replaced by a no-op).   python tests/perf/latency_breakdown.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import pycwt_amd
+from pycwt_amd import wavelet
+
+
+def per_call(f, n):
+    f()
+    t = time.perf_counter()
+    for _ in range(n):
+        f()
+    return (time.perf_counter() - t) / n * 1e6
+
+
+x = np.random.default_rng(0).standard_normal(504)
+f = lambda: pycwt_amd.cwt(x, 0.25, 1 / 12, wavelet="morlet")
+for _ in range(20):
+    f()
+whole = min(per_call(f, 500) for _ in range(5))
+plan = next(iter(wavelet._plans.values()))
+sj = f()[1]
+inner = min(per_call(lambda: plan.execute_host(x, 0, 6.0, 0.25, sj), 500) for _ in range(5))
+real = plan.lib.cwt_execute_host
+plan.lib.cwt_execute_host = lambda *a: 0
+stub = min(per_call(f, 2000) for _ in range(3))
+plan.lib.cwt_execute_host = real
+print(f"pycwt_amd.cwt 504 x {sj.size}: {whole:.1f} us per call; Plan.execute_host alone {inner:.1f} us; "
+      f"Python with the C call stubbed {stub:.1f} us")

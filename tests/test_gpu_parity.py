@@ -898,3 +898,45 @@ def test_config4_full_batch_parseval_on_every_row(hip_library):
     print(f"config 4, Parseval on all {nb * rows} rows: worst relative deviation {rel.max():.2e} at signal {b}, scale {j} "
           f"({classes[j]})")
     assert rel.max() < 1e-10, (b, j, classes[j], rel.max())
+
+
+@pytest.mark.parametrize("prec,tol", [(64, 2e-14), (32, 2e-5)])
+@pytest.mark.parametrize("name", ["morlet", "paul", "dog"])
+@pytest.mark.parametrize("n0", [16, 504, 1000, 4096])
+def test_short_calls_on_gpu(hip_library, prec, tol, name, n0):
+    """Transforms that fit one workgroup: one launch that reads the signal and writes W through page-locked host memory
+    (cwt_execute_host; the default), against the two-launch / staged forms and the oracle."""
+    kind, param = MOTHERS[name]
+    m = orc.Mother(kind, param)
+    N = 1 << int(np.ceil(np.log2(n0)))
+    x = np.random.default_rng(n0).standard_normal(n0)
+    sj = grid(n0, 0.25, m, 41)
+    out = {}
+    for label, opts in (("fused", {}), ("apart", {"fuse_small": 0}), ("staged", {"host_direct": 0})):
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=hip_library, options=opts)
+        out[label] = plan.execute_host(x, kind, param, 0.25, sj)
+        assert set(plan.row_classes()) == {"single_wg"}
+        plan.close()
+    for other in ("apart", "staged"):
+        scale = np.abs(out[other][0]).max()
+        assert np.abs(out["fused"][0] - out[other][0]).max() <= (4e-16 if prec == 64 else 3e-7) * scale
+        np.testing.assert_array_equal(out["fused"][1], out[other][1])
+    per_row, l2 = row_errors(out["fused"][0], orc.cwt_rows(x, 0.25, sj, m, N=N)[:, :n0])
+    assert per_row.max() < tol and l2 < tol, (per_row.max(), l2)
+
+
+def test_shim_results_live_in_their_own_page_locked_buffers(hip_library):
+    g = load_golden("nino3_simple")
+    outs = [pycwt_amd.cwt(g["x"] * k, 0.25, 1 / 12, 0.5, 84, "morlet") for k in (1.0, 2.0, 3.0)]
+    assert len({o[0].ctypes.data for o in outs}) == 3
+    for k, o in zip((1.0, 2.0, 3.0), outs):
+        per_row, _ = row_errors(o[0], k * g["W"])
+        assert per_row.max() < 1e-12
+    check_tuple(outs[0], g, 1e-12)
+    pool = hip_library.pinned
+    assert pool.total > 0
+    before = sum(len(v) for v in pool.free.values())
+    del outs, o
+    import gc
+    gc.collect()
+    assert sum(len(v) for v in pool.free.values()) >= before + 3

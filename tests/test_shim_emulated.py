@@ -37,6 +37,19 @@ def test_nino3_default_scales_and_string_mother(emulated):
     check_tuple(out, g)
 
 
+def test_repeated_calls_return_private_arrays(emulated):
+    """The scale grid / cone of influence of a repeated call come from a cache: what a caller does to the returned arrays
+    (the reference hands out fresh ones every call) must not show up in the next call."""
+    g = load_golden("nino3_default")
+    first = pycwt_amd.cwt(g["x"], 0.25, wavelet="morlet")
+    for a in first[1:4] + first[5:]:
+        a[...] = -1.0
+    check_tuple(pycwt_amd.cwt(g["x"], 0.25, wavelet="morlet"), g)
+    check_tuple(pycwt_amd.cwt(g["x"], 0.25, wavelet=pycwt_amd.Morlet(6)), g)
+    other = pycwt_amd.cwt(g["x"], 0.25, wavelet=pycwt_amd.Morlet(5))              # a different parameter is a different grid
+    assert other[2].shape != g["freqs"].shape or not np.allclose(other[2], g["freqs"])
+
+
 @pytest.mark.parametrize("name,cls", [("morlet", pycwt_amd.Morlet), ("paul", pycwt_amd.Paul),
                                       ("dog", pycwt_amd.DOG)])
 def test_small_fixture_per_mother_including_nan_row_drop(emulated, name, cls):
