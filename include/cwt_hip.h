@@ -107,10 +107,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)
  *   "ols_fwd_weight" cost of one block spectrum in percent of one row's block transform (halo class grouping; 100)
- *   "fuse_small"   0 = transforms that fit one workgroup launch the forward FFT and the rows separately (default 1: one
- *                  launch, k_small_signal; cwt_transform and cwt_execute_host)
- *   "host_direct"  0 = cwt_execute_host stages such transforms through device buffers and copy operations (default 1: the
- *                  kernel reads and writes page-locked host memory itself)
+ *   "host_direct"  0 = cwt_execute_host stages transforms that fit one workgroup per row through device buffers and copy
+ *                  operations like the longer ones (default 1: their kernels read the signal from and write W into
+ *                  page-locked host memory themselves)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
@@ -303,9 +302,9 @@ int cwt_coherence_histogram(cwt_plan* plan, const void* r2_dev, int64_t ld, int 
 /* ---- host convenience: what the ctypes shim of pycwt.cwt() calls ---------
  * x_host: n0 reals of the plan's precision.  W_host: nrows x n0 complex (may be
  * NULL).  xhat_host: nfft complex (may be NULL) for the 5th return value
- * (wavelet.py:123-124).  Synchronous.  Transforms that fit one workgroup
- * (nfft <= 4096) run as ONE kernel that reads the signal and writes the spectrum
- * and W through page-locked host memory (options "fuse_small", "host_direct").  */
+ * (wavelet.py:123-124).  Synchronous.  Transforms that fit one workgroup per
+ * row (nfft <= 4096) read the signal and write W through page-locked host memory,
+ * without copy operations (option "host_direct", cwt_host_malloc).            */
 int cwt_execute_host(cwt_plan* plan, const void* x_host, int64_t n0, int mother, double param,
                      double dt, const double* scales_host, int nrows, void* W_host,
                      void* xhat_host);

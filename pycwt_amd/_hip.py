@@ -140,7 +140,7 @@ class PinnedPool:
     the array and every view of it are garbage; at most LIMIT bytes are ever pinned, then (or for results above ONE)
     `empty` returns None and the caller uses pageable memory."""
     LIMIT = 256 << 20
-    ONE = 4 << 20
+    ONE = 16 << 20
     GRAIN = 1 << 16
 
     def __init__(self, lib):

@@ -195,8 +195,7 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
-  int fuse_small = 1;      // transforms that fit one workgroup: forward FFT and rows in one launch (k_small_signal)
-  int host_direct = 1;     // cwt_execute_host, such transforms: the kernel reads the signal from / writes W into page-locked host memory
+  int host_direct = 1;     // cwt_execute_host, transforms that fit one workgroup: the kernels read the signal from / write W into page-locked host memory
   int ols_hold = 0;        // 1 = the overlap-save rows wait for the coefficients of the polynomial rows (tuning; see rows_launch)
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
                            // HIP graph on its second occurrence and replay it from the third on
@@ -1822,7 +1821,6 @@ int set_func_attrs() {
   // opt-in attribute.  A refusal is not fatal here: a launch that really needs it reports the error.
   const int big = 128 * 1024;
   const void* fns[] = {reinterpret_cast<const void*>(&k_small<T, IN_REAL>),
-                       reinterpret_cast<const void*>(&k_small_signal<T>),
                        reinterpret_cast<const void*>(&k_small<T, IN_SPECTRUM>),
                        reinterpret_cast<const void*>(&k_small<T, IN_CPLX>),
                        reinterpret_cast<const void*>(&k_pass_a<T, IN_CPLX>),
@@ -2053,7 +2051,6 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols") p->ols = value != 0;
   else if (k == "graph") p->graph = value != 0;
   else if (k == "ols_hold") p->ols_hold = value != 0;
-  else if (k == "fuse_small") p->fuse_small = value != 0;
   else if (k == "host_direct") p->host_direct = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
@@ -2302,28 +2299,6 @@ int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, 
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
 }
 
-// Transform of one real signal that fits one workgroup: forward FFT and rows in a single launch (k_small_signal).
-bool fused_small(const cwt_plan* p, int nrows) {
-  return p->fuse_small && !p->profile && p->logN > 3 && p->logN <= p->loglmax && p->rt->n_small == nrows;
-}
-
-template <typename T>
-int launch_small_signal(cwt_plan* p, const void* x, int64_t n0, const Mother& mo, int nrows, void* xhat_out, void* W,
-                        int64_t ldw, int64_t ncols) {
-  int rc = check_geometry(p);
-  if (rc) return rc;
-  const int logN = p->logN;
-  const int logTB = std::max(0, std::min(12, p->log_wg_points) - logN);
-  const int TB = 1 << logTB;
-  const int threads = TB << (logN - 4);
-  const size_t lds = (size_t(TB) << logN) * sizeof(T);
-  return timed_launch(p, KC_SMALL, [&] {
-    hipLaunchKernelGGL((k_small_signal<T>), dim3((nrows + TB - 1) / TB), dim3(threads), lds, p->stream,
-                       static_cast<const T*>(x), p->rt->rows_dev, nrows, mo, tw_table<T>(p, logN), logN, logTB, long(n0),
-                       static_cast<cplx<T>*>(xhat_out), static_cast<cplx<T>*>(W), long(ldw), long(ncols));
-  });
-}
-
 // The overlap-save rows need the signal only: cwt_transform queues them on side stream 1 BEFORE the forward FFT, so
 // that they run beside it and beside the two-pass chain; rows_impl then skips them and joins the stream at its end.
 template <typename T>
@@ -2356,7 +2331,6 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
-  const bool wants_xhat = xhat_dev != nullptr;
   const bool only_ols = !xhat_dev && p->rt->n_ols == nrows;      // every row is an overlap-save row on the real signal
   if (!xhat_dev && !only_ols) {
     rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * 2 * p->esize(), p->stream);
@@ -2364,9 +2338,6 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
     xhat_dev = p->hxhat;
   }
   const Mother mo = mother_of(mother, param);
-  if (fused_small(p, nrows))
-    return p->prec == 64 ? launch_small_signal<double>(p, x_dev, n0, mo, nrows, wants_xhat ? xhat_dev : nullptr, W_dev, ldw, ncols)
-                         : launch_small_signal<float>(p, x_dev, n0, mo, nrows, wants_xhat ? xhat_dev : nullptr, W_dev, ldw, ncols);
   auto enqueue = [&]() -> int {
     p->ols_launched = 0;
     int r = CWT_OK;
@@ -2928,11 +2899,12 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
   const size_t es = p->esize();
-  // A transform that fits one workgroup (the reference's canonical 504-point call) is ONE kernel here: it reads the signal
-  // from the plan's page-locked staging buffer and writes the spectrum and W over PCIe itself -- into W_host when that is
-  // a cwt_host_malloc buffer, else into the staging buffer (then one memcpy).  No copy operations, one synchronisation:
-  // 45 us against 83 (504 x 97, fp64) [measured, profiles/r04_latency.txt].
-  if (W_host && p->host_direct && p->fuse_small && !p->profile && p->logN > 3 && p->logN <= p->loglmax) {
+  // A transform that fits one workgroup per row (the reference's canonical 504-point call: 4 KB in, 0.8 MB out) is all
+  // latency, and copy operations are the larger part of it.  Here it has none: the forward FFT reads the signal from the
+  // plan's page-locked staging buffer, the row kernel writes W over PCIe itself -- into W_host when that is a
+  // cwt_host_malloc buffer, else into the staging buffer (then one memcpy) -- and only the spectrum (nfft values) is
+  // copied.  45 us against 83 at 504 x 97, fp64 [measured, profiles/r04_latency.txt; tools/microbench/host_latency.cpp].
+  if (W_host && p->host_direct && !p->profile && p->logN > 3 && p->logN <= p->loglmax) {
     const size_t in_b = (size_t(n0) * es + 255) & ~size_t(255), xh_b = size_t(p->N) * 2 * es;
     const size_t w_b = size_t(nrows) * size_t(n0) * 2 * es;
     const bool w_direct = is_pinned(W_host, w_b);
@@ -2945,21 +2917,18 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
         const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
         if (floor_tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = floor_tol; }
       }
-      int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, n0, n0);
+      int rc = grow(&p->hxhat, &p->hxhat_bytes, xh_b, p->stream);
       if (rc) return rc;
-      if (fused_small(p, nrows)) {
-        char* stage = static_cast<char*>(p->hstage);
-        std::memcpy(stage, x_host, size_t(n0) * es);
-        void* W_out = w_direct ? W_host : stage + in_b + xh_b;
-        const Mother mo = mother_of(mother, param);
-        rc = p->prec == 64 ? launch_small_signal<double>(p, stage, n0, mo, nrows, xhat_host ? stage + in_b : nullptr, W_out, n0, n0)
-                           : launch_small_signal<float>(p, stage, n0, mo, nrows, xhat_host ? stage + in_b : nullptr, W_out, n0, n0);
-        if (rc) return rc;
-        HIPCHECK(hipStreamSynchronize(p->stream));
-        if (xhat_host) std::memcpy(xhat_host, stage + in_b, xh_b);
-        if (!w_direct) std::memcpy(W_host, W_out, w_b);
-        return CWT_OK;
-      }
+      char* stage = static_cast<char*>(p->hstage);
+      std::memcpy(stage, x_host, size_t(n0) * es);
+      void* W_out = w_direct ? W_host : stage + in_b + xh_b;
+      rc = cwt_transform(p, stage, n0, mother, param, dt, scales, nrows, p->hxhat, W_out, n0, n0);
+      if (rc) return rc;
+      if (xhat_host) HIPCHECK(hipMemcpyAsync(stage + in_b, p->hxhat, xh_b, hipMemcpyDeviceToHost, p->stream));
+      HIPCHECK(hipStreamSynchronize(p->stream));
+      if (xhat_host) std::memcpy(xhat_host, stage + in_b, xh_b);
+      if (!w_direct) std::memcpy(W_host, W_out, w_b);
+      return CWT_OK;
     }
   }
   int rc = grow(&p->hx, &p->hx_bytes, size_t(n0) * es, p->stream);

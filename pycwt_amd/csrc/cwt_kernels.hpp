@@ -235,64 +235,6 @@ k_small(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows
   }
 }
 
-// k_small_signal: k_small<IN_REAL> and k_small<IN_SPECTRUM> in ONE launch, for a single real signal and a built-in
-// mother: every group of threads transforms the signal itself and goes on with its row.  A transform that fits one
-// workgroup is all launch latency (the reference's canonical call: 504 samples x 97 scales); a second, dependent launch
-// costs ~14 us, the redundant FFTs nothing.  The signal is read ONCE per workgroup (it may lie in page-locked host
-// memory, as may xhat_out and out: cwt_execute_host) and handed to the other groups through LDS; the spectrum sits in the
-// registers in exactly the slots the inverse transform wants its input in.  xhat_out (may be NULL): written by group 0
-// of workgroup 0.
-template <typename T>
-__global__ void __launch_bounds__(CWT_MAX_THREADS)
-k_small_signal(const T* __restrict__ x, const RowDesc* __restrict__ rows, int nrows, Mother mo,
-               const cplx<T>* __restrict__ tw, int logN, int logTB, long n0, cplx<T>* __restrict__ xhat_out,
-               cplx<T>* __restrict__ out, long ldw, long ncols) {
-  HIP_DYNAMIC_SHARED(double2, lds_raw)
-  T* lds = reinterpret_cast<T*>(lds_raw);
-  const int N = 1 << logN, logNT = logN - 4, NT = 1 << logNT;
-  Geo<T, false> g;
-  g.logL = logN; g.logTB = logTB;
-  g.j = threadIdx.x & (NT - 1);
-  g.t = threadIdx.x >> logNT;
-  const int row = blockIdx.x * (1 << logTB) + g.t;
-  const bool live = row < nrows;
-  T re[16], im[16];
-  if (g.t == 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int k = g.j + (e << logNT);
-      lds[k] = k < n0 ? x[k] : T(0);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { re[e] = lds[g.j + (e << logNT)]; im[e] = T(0); }
-  __syncthreads();
-  wg_ifft<T, false>(re, im, lds, g, tw);                  // xhat[k] = (re, -im) at k = j + e NT
-  if (xhat_out && blockIdx.x == 0 && g.t == 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) xhat_out[g.j + (e << logNT)] = mk<T>(re[e], -im[e]);
-  }
-  RowDesc rd;
-  if (live) rd = rows[row]; else { rd.nband = 0; rd.k_lo = 0; rd.a = 0; rd.amp_re = 0; rd.amp_im = 0; rd.out_row = 0; rd.spec_off = 0; rd.tab_off = 0; rd.aux_off = 0; rd.nyq_re = 0; rd.nyq_im = 0; }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int ks = signed_bin(g.j + (e << logNT), N);
-    cplx<T> v = mk<T>(T(0), T(0));
-    if (unsigned(ks - rd.k_lo) < unsigned(rd.nband)) v = filter_value<T>(mk<T>(re[e], -im[e]), rd, mo, ks);
-    re[e] = v.x; im[e] = v.y;
-  }
-  __syncthreads();
-  wg_ifft<T, false>(re, im, lds, g, tw);
-  if (!live) return;
-  const long orow = long(rd.out_row);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const long m = g.j + (e << logNT);
-    if (m < ncols) out[orow * ldw + m] = mk<T>(re[e], im[e]);
-  }
-}
-
 // k_direct: N <= 8.  One thread per output element.
 template <typename T, int MODE>
 __global__ void k_direct(const void* __restrict__ in, const RowDesc* __restrict__ rows, int nrows,

@@ -51,33 +51,50 @@ int main(int argc, char** argv) {
 
   line("cwt_execute_host (W and spectrum)", [&] { cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, W.data(), xh.data()); });
   line("cwt_execute_host (W only)", [&] { cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, W.data(), nullptr); });
+  {
+    void* Wp = nullptr;
+    CK(cwt_host_malloc(&Wp, wb));
+    line("cwt_execute_host, W in a cwt_host_malloc buffer", [&] { cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, Wp, xh.data()); });
+    std::printf("  same bytes as into pageable memory: %s\n", std::memcmp(W.data(), Wp, wb) ? "NO" : "yes");
+    for (int wg : {512, 1024, 2048, 4096}) {               // rows per workgroup of the row kernel = wg / N
+      if (wg < N) continue;
+      CK(cwt_plan_set_option(p, "wg_points", wg));
+      char what[96];
+      std::snprintf(what, sizeof what, "  ... with %d-point workgroups (%d rows each)", wg, int(wg / N));
+      line(what, [&] { cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, Wp, xh.data()); });
+    }
+    CK(cwt_host_free(Wp));
+    CK(cwt_plan_set_option(p, "host_direct", 0));
+    line("cwt_execute_host, option host_direct = 0 (copies: round 3)", [&] { cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, W.data(), xh.data()); });
+    CK(cwt_plan_set_option(p, "host_direct", 1));
+  }
   line("empty stream synchronize", [&] { sync(); });
   line("H2D 4 KB from pinned + sync", [&] { (void)hipMemcpyAsync(xd, pin, xb, hipMemcpyHostToDevice, st); sync(); });
   line("cwt_transform on device buffers + sync", [&] { cwt_transform(p, xd, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, Wd, n0, n0); sync(); });
   line("cwt_transform, host API time only (no sync)", [&] { cwt_transform(p, xd, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, Wd, n0, n0); });
   sync();
   line("cwt_forward_fft + sync", [&] { cwt_forward_fft(p, xd, n0, xhd); sync(); });
-  line("D2H W to pinned + sync", [&] { (void)hipMemcpyAsync(pinc + 65536, Wd, wb, hipMemcpyDeviceToHost, st); sync(); });
-  line("D2H spectrum to pinned + sync", [&] { (void)hipMemcpyAsync(pinc + 8192, xhd, hb, hipMemcpyDeviceToHost, st); sync(); });
-  line("memcpy W pinned -> pageable", [&] { std::memcpy(W.data(), pinc + 65536, wb); });
+  line("D2H W to pinned + sync", [&] { (void)hipMemcpyAsync(pinc + (2 << 20), Wd, wb, hipMemcpyDeviceToHost, st); sync(); });
+  line("D2H spectrum to pinned + sync", [&] { (void)hipMemcpyAsync(pinc + (1 << 20), xhd, hb, hipMemcpyDeviceToHost, st); sync(); });
+  line("memcpy W pinned -> pageable", [&] { std::memcpy(W.data(), pinc + (2 << 20), wb); });
   line("H2D + transform + 2 x D2H + sync (what execute_host queues)", [&] {
     (void)hipMemcpyAsync(xd, pin, xb, hipMemcpyHostToDevice, st);
     cwt_transform(p, xd, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, Wd, n0, n0);
-    (void)hipMemcpyAsync(pinc + 8192, xhd, hb, hipMemcpyDeviceToHost, st);
-    (void)hipMemcpyAsync(pinc + 65536, Wd, wb, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(pinc + (1 << 20), xhd, hb, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(pinc + (2 << 20), Wd, wb, hipMemcpyDeviceToHost, st);
     sync(); });
   // kernels on the page-locked buffer itself: signal read over PCIe, W (and the spectrum) written over PCIe
   std::memcpy(pin, x.data(), xb);
-  line("cwt_transform: x, W in pinned host memory; spectrum on device", [&] { cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + 65536, n0, n0); sync(); });
-  line("cwt_transform: x, W, spectrum all in pinned host memory", [&] { cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, pinc + 8192, pinc + 65536, n0, n0); sync(); });
-  line("cwt_transform: x on device, W pinned", [&] { cwt_transform(p, xd, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + 65536, n0, n0); sync(); });
+  line("cwt_transform: x, W in pinned host memory; spectrum on device", [&] { cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + (2 << 20), n0, n0); sync(); });
+  line("cwt_transform: x, W, spectrum all in pinned host memory", [&] { cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, pinc + (1 << 20), pinc + (2 << 20), n0, n0); sync(); });
+  line("cwt_transform: x on device, W pinned", [&] { cwt_transform(p, xd, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + (2 << 20), n0, n0); sync(); });
   line("pinned x, W + D2H spectrum", [&] {
-    cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + 65536, n0, n0);
-    (void)hipMemcpyAsync(pinc + 8192, xhd, hb, hipMemcpyDeviceToHost, st); sync(); });
+    cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, xhd, pinc + (2 << 20), n0, n0);
+    (void)hipMemcpyAsync(pinc + (1 << 20), xhd, hb, hipMemcpyDeviceToHost, st); sync(); });
   // results agree?
   cwt_execute_host(p, x.data(), n0, 0, 6.0, 0.25, sj.data(), rows, W.data(), xh.data());
-  cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, pinc + 8192, pinc + 65536, n0, n0); sync();
+  cwt_transform(p, pin, n0, 0, 6.0, 0.25, sj.data(), rows, pinc + (1 << 20), pinc + (2 << 20), n0, n0); sync();
   std::printf("pinned-memory result identical to cwt_execute_host: W %s, spectrum %s\n",
-              std::memcmp(W.data(), pinc + 65536, wb) ? "NO" : "yes", std::memcmp(xh.data(), pinc + 8192, hb) ? "NO" : "yes");
+              std::memcmp(W.data(), pinc + (2 << 20), wb) ? "NO" : "yes", std::memcmp(xh.data(), pinc + (1 << 20), hb) ? "NO" : "yes");
   return 0;
 }
