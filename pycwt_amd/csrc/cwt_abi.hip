@@ -3055,10 +3055,12 @@ extern "C++" {
 namespace {
 // Cost model of one rank's step, microseconds at N = 2^20: per kernel class a fixed part (launch ramp and tail; for the
 // overlap-save classes the block spectra of that tile size) + a per-row part.  Fitted to the per-class launch durations of
-// bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt.
+// bench.py on BASELINE configs 2 / 3 (profiles/r03_per_class.txt) and the per-rank runs of profiles/r03_shards.txt; the
+// overlap-save, band-passed and polynomial terms of fp64 refitted (least squares) to the 15 per-rank runs of
+// profiles/r04_shards.txt.
 struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term,
                    aols_fixed, aols_row, poly_fixed, poly_row, poly_coef; };
-constexpr ShardCost kShardCost64 = {28.0, 18.0, 9.8, 30.0, 6.1, 32.0, 4.0, 23.0, 3.5, 8.0, 2.85, 0.9, 45.0, 3.8, 25.0, 2.7, 2.2};
+constexpr ShardCost kShardCost64 = {30.0, 18.0, 9.8, 30.0, 6.1, 22.0, 3.25, 44.0, 3.2, 8.0, 2.85, 0.9, 32.0, 2.9, 12.5, 2.67, 2.7};
 constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55, 40.0, 2.3, 22.0, 1.4, 1.1};
 
 // Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
