@@ -278,6 +278,7 @@ struct cwt_plan {
     long poly_coef_elems = 0, poly_band_elems = 0;
     int poly_max_logk = 8;
     int n_aols = 0, aols_first = 0, aux_first = -1, aols_logp = 12;
+    int aols_nbatch = 1;                 // signals of a batched call: aols_geom.nrows rows and one mask pseudo-row (aux_first + b) each
     AolsGeom aols_geom{};
     long aols_wgs = 0, aols_gt_elems = 0;
     void* agt_dev = nullptr;             // their (real) filter tables
@@ -640,6 +641,9 @@ int mother_constant(int mother, double param, double* cre, double* cim) {
   return CWT_OK;
 }
 
+// Entries of a plan's row tables: max_rows rows + the pseudo-rows some forms add.
+size_t table_capacity(int max_rows) { return size_t(max_rows) + size_t(max_rows) / 3 + 4; }
+
 // Row table for W[j,:] = IFFT_N( spec_j[k] * (amp_j * profile(a_j * signed_bin(k))) ), spec_j = spec + j*spec_ld.
 // a_j = profile argument per bin, amp_j = complex amplitude WITHOUT the 1/N of the inverse FFT.
 // ols_ncols > 0: the caller also has the real signal (cwt_transform): time-compact rows may take the overlap-save
@@ -689,8 +693,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*): needs the spectrum only;
   // Morlet and Paul (a real mother constant and nothing to keep on the masked-out bins), one shared spectrum
   // DOG (order >= 1): also, but only when the call hands over the REAL signal (its negative bins are the mirror image then)
+  // a batch (rows_per_signal > 0: the same rows for every signal): one mask pseudo-row and one set of block spectra per
+  // signal; like the overlap-save rows the form pays from shorter transforms there, the threshold counts the batch
+  const int aols_nbatch = rows_per_signal > 0 ? std::max(1, nrows / rows_per_signal) : 1;
+  const bool aols_layout = rows_per_signal > 0 ? (nrows % rows_per_signal == 0 && size_t(nrows) + size_t(aols_nbatch) <= table_capacity(p->max_rows))
+                                               : spec_ld == 0;
   const bool aols_ok = p->ols && p->aols && out_ncols > 0 && p->use_ct && logP == (p->prec == 64 ? 13 : 14) &&
-                       p->logN >= p->ols_min_logn && rows_per_signal == 0 && spec_ld == 0 && !use_small &&
+                       p->logN + ilog2(aols_nbatch) >= p->ols_min_logn && p->logN >= 15 && aols_layout && !use_small &&
                        (mother == MOTHER_MORLET || mother == MOTHER_PAUL ||
                         (mother == MOTHER_DOG && param >= 1 && ols_ncols > 0));
   double fc_lo = 0, fc_hi = 0;
@@ -896,23 +905,28 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     }
     std::vector<int> halos(wide_rows.size(), 0);
     int hmax_seen = 0, cnt = 0;
+    const int rps = rows_per_signal > 0 ? rows_per_signal : nrows;
     if (geom_ok) {
       const double eps = std::max(tol.halo, p->prec == 64 ? 2e-14 : 5e-7);
+      std::vector<int> halo_of_scale(size_t(rps), -1);     // (a numeric tail search each: once per scale, not per signal)
       for (size_t i = 0; i < wide_rows.size(); ++i) {
         if (!wide_clipped[i]) continue;
-        halos[i] = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512);
+        int& h = halo_of_scale[size_t(wide_rows[i].out_row % rps)];
+        if (h < 0) h = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512);
+        halos[i] = h;
         if (halos[i]) { ++cnt; hmax_seen = std::max(hmax_seen, halos[i]); }
       }
     }
-    if (geom_ok && cnt >= std::max(1, p->aols_min_rows)) {
+    if (geom_ok && cnt % aols_nbatch == 0 && cnt / aols_nbatch >= std::max(1, p->aols_min_rows)) {
       aols_logp = 12;                                      // 4096-point tiles: four block transforms in flight per CU
       const int P = 1 << aols_logp, L = P - 2 * hmax_seen;
       ag.halo = hmax_seen;
-      ag.nrows = cnt;
+      ag.nrows = cnt / aols_nbatch;                         // per signal
       ag.nblocks = int((out_ncols + L - 1) / L);
       ag.ksp = int(std::ceil(ag.f_s * double(P)));
       std::vector<RowDesc> keep;
       long toff = 0;
+      std::vector<long> tab_of_scale(size_t(rps), -1);     // one filter table per scale, shared by the signals
       for (size_t i = 0; i < wide_rows.size(); ++i) {
         if (!halos[i]) { keep.push_back(wide_rows[i]); continue; }
         RowDesc o = wide_rows[i];
@@ -931,9 +945,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           o.nyq_re = amp_re[o.out_row] * pn;                // F_j at the Nyquist bin (w = -pi / dt, wavelet.py:94) / N
           o.nyq_im = amp_im[o.out_row] * pn;
         }
-        o.spec_off = 0;
-        o.tab_off = toff;
-        toff += P;
+        long& t = tab_of_scale[size_t(o.out_row % rps)];
+        if (t < 0) { t = toff; toff += P; }
+        o.tab_off = t;                                      // (spec_off stays the offset of the row's signal in the spectra)
         aols_rows.push_back(o);
       }
       wide_rows.swap(keep);
@@ -1100,13 +1114,18 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     p->rt->aols_logp = aols_logp;
     p->rt->aols_geom = ag;
     p->rt->aols_wgs = long((ag.nblocks + 7) / 8) * 8 * ag.nrows;
-    p->rt->aols_gt_elems = long(aols_rows.size()) << aols_logp;
+    p->rt->aols_gt_elems = long(ag.nrows) << aols_logp;
+    p->rt->aols_nbatch = aols_nbatch;
     RowDesc m{};                                          // (zero-initialised: no Nyquist term) the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)
     m.a = 0.0; m.amp_re = 1.0 / double(N); m.amp_im = 0.0;
     m.k_lo = aols_ks; m.nband = int(N / 2) - aols_ks;
-    m.out_row = 0; m.logK = 0; m.nterms = 1; m.spec_off = 0; m.tab_off = 0;
+    m.logK = 0; m.nterms = 1; m.tab_off = 0;
     p->rt->aux_first = int(p->rt->table.size());
-    p->rt->table.push_back(m);
+    for (int b = 0; b < aols_nbatch; ++b) {               // one per signal
+      m.out_row = b;
+      m.spec_off = rows_per_signal > 0 ? long(spec_ld) * b : 0;
+      p->rt->table.push_back(m);
+    }
   }
   // polynomial rows: by K', then by degree; coefficient offsets; the workgroups of k_poly_coef per class
   p->rt->poly_first = int(p->rt->table.size());
@@ -1527,39 +1546,46 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
-  int rc = grow(&p->xm, &p->xm_bytes, size_t(p->N) * sizeof(cplx<T>), st);
-  if (!rc) rc = grow(&p->xsa, &p->xsa_bytes, size_t(g.nblocks) * size_t(P + 8) * sizeof(cplx<T>), st);
-  if (!rc) rc = ensure_z(p, 1);
+  // a batch goes through in chunks of signals: the band-passed signals and their block spectra of one chunk stay in the
+  // Infinity Cache between the four kernels (2 x 16 N + ~18 N bytes per signal)
+  const int nb = rt->aols_nbatch;
+  const int chunk = std::max(1, std::min(nb, std::min(balanced_chunk(p, nb), int((size_t(96) << 20) / (size_t(p->N) * sizeof(cplx<T>))))));
+  int rc = grow(&p->xm, &p->xm_bytes, size_t(chunk) * size_t(p->N) * sizeof(cplx<T>), st);
+  if (!rc) rc = grow(&p->xsa, &p->xsa_bytes, size_t(chunk) * size_t(g.nblocks) * size_t(P + 8) * sizeof(cplx<T>), st);
+  if (!rc) rc = ensure_z(p, chunk);
   if (rc) return rc;
   const int logK = two_pass_logk(p), logR = p->logN - logK;
   Mother one;
   one.kind = MOTHER_DOG; one.m = 0; one.p = 0.0; one.table = nullptr;       // profile(0 * k) = 1
   cplx<T>* Z = static_cast<cplx<T>*>(p->Z);
   cplx<T>* xm = static_cast<cplx<T>*>(p->xm);
-  bool ok = true;
-  rc = timed_launch(p, KC_AOLS_PRE, [&] {
-    ok = try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rt->rows_dev + rt->aux_first, 1, one, 0L, 0L, Z, st);
-  }, st);
-  if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-  if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
-    ok = try_pass_b_ct<T, false>(p, logK, nullptr, 1, xm, p->N, p->N, Z, st);
-  }, st);
-  if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-  if (rc) return rc;
   static const bool once = (allow_big_lds(&k_aols_fwd<T, LOGP>), allow_big_lds(&k_aols_rows<T, LOGP>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
-  rc = timed_launch(p, KC_AOLS_PRE, [&] {
-    hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks)), dim3(1 << (LOGP - 4)), lds, st, xm, p->logN, g.halo,
-                       static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
-  }, st);
-  if (rc) return rc;
-  return timed_launch(p, KC_AOLS, [&] {
-    hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs)), dim3(1 << (LOGP - 4)), lds, st,
-                       static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first,
-                       static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
-                       static_cast<const cplx<T>*>(xhat_dev) + (p->N >> 1), W, long(ldw), long(ncols));
-  }, st);
+  for (int b0 = 0; b0 < nb; b0 += chunk) {
+    const int cnt = std::min(chunk, nb - b0);
+    bool ok = true;
+    rc = timed_launch(p, KC_AOLS_PRE, [&] {
+      ok = try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rt->rows_dev + rt->aux_first + b0, cnt, one, 0L, 0L, Z, st);
+    }, st);
+    if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
+    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+      ok = try_pass_b_ct<T, false>(p, logK, nullptr, cnt, xm, p->N, p->N, Z, st);
+    }, st);
+    if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
+    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+      hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st, xm,
+                         p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
+    }, st);
+    if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
+      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st,
+                         static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
+                         static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
+                         static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W, long(ldw), long(ncols));
+    }, st);
+    if (rc) return rc;
+  }
+  return CWT_OK;
 }
 template <typename T>
 int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
@@ -1955,10 +1981,10 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
   for (auto& t : p->slots) {
-    // (+ 4: pseudo-rows such as the mask of the k_aols rows)
-    if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), size_t(max_rows + 4) * sizeof(RowDesc)) != hipSuccess)
+    // (+ max_rows / 3 + 4: pseudo-rows -- the mask of the k_aols rows, one per signal of a batch)
+    if (!rc && hipMalloc(reinterpret_cast<void**>(&t.rows_dev), table_capacity(max_rows) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "row table allocation failed");
-    if (!rc && hipHostMalloc(reinterpret_cast<void**>(&t.rows_pinned), size_t(max_rows + 4) * sizeof(RowDesc)) != hipSuccess)
+    if (!rc && hipHostMalloc(reinterpret_cast<void**>(&t.rows_pinned), table_capacity(max_rows) * sizeof(RowDesc)) != hipSuccess)
       rc = fail(CWT_ENOMEM, "pinned row table allocation failed");
     if (!rc && hipEventCreate(&t.uploaded) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   }
@@ -2245,7 +2271,7 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   int rc = grow(&t->agt_dev, &t->agt_bytes, size_t(t->aols_gt_elems) * sizeof(T), p->stream);
   if (rc) return rc;
   const int P = 1 << t->aols_logp;
-  const dim3 grid(P / 256, t->n_aols), block(256);
+  const dim3 grid(P / 256, t->aols_geom.nrows), block(256);     // (a batch: the tables of the first signal's rows serve all)
   const RowDesc* rows = t->rows_dev + t->aols_first;
   T* gt = static_cast<T*>(t->agt_dev);
   if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
@@ -2468,10 +2494,12 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
       ai[j] = norm * cim;
     }
     // as cwt_transform_rows_batch, with the signals at hand: time-compact rows may take the overlap-save form
-    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), p->N, total, nullptr, nullptr, nrows, -1, ncols);
+    rc = build_row_table(p, mother, param, a.data(), ar.data(), ai.data(), p->N, total, nullptr, nullptr, nrows, -1, ncols, ncols);
     if (!rc) rc = upload_row_table(p, key);
     if (!rc && p->rt->n_ols)
       rc = p->prec == 64 ? fill_ols_tables<double>(p, mother_of(mother, param)) : fill_ols_tables<float>(p, mother_of(mother, param));
+    if (!rc && p->rt->n_aols)
+      rc = p->prec == 64 ? fill_aols_tables<double>(p, mother_of(mother, param)) : fill_aols_tables<float>(p, mother_of(mother, param));
     if (rc) { p->rt->key.clear(); return rc; }
   }
   set_split(p);
@@ -3025,13 +3053,14 @@ int cwt_plan_timings(cwt_plan* p, int cap, const char** names, double* total_ms,
 int cwt_plan_row_classes(cwt_plan* p, int* codes, int cap, int* n) {
   if (!p || !n) return fail(CWT_EINVAL, "NULL argument");
   const int total = int(p->rt->table.size());
-  *n = total - (p->rt->aux_first >= 0 ? 1 : 0);
+  const int n_aux = p->rt->aux_first >= 0 ? p->rt->aols_nbatch : 0;
+  *n = total - n_aux;
   if (!codes) return CWT_OK;
   for (int i = 0; i < total; ++i) {
     const RowDesc& rd = p->rt->table[i];
     // 0 single-workgroup, 1 band-limited, 2 band-limited K = 2048, 3 two-pass, 4 overlap-save, 5 overlap-save on half-size tiles
     const int small_end = p->rt->ols_first + (p->rt->ols_grp[0].logp != p->rt->ols_grp[1].logp ? p->rt->ols_grp[0].nrows : 0);
-    if (i == p->rt->aux_first) continue;                 // the mask pseudo-row of the k_aols rows
+    if (n_aux && i >= p->rt->aux_first && i < p->rt->aux_first + n_aux) continue;      // the mask pseudo-rows of the k_aols rows
     // ... 6 overlap-save on the band-passed complex signal (rows clipped at Nyquist)
     // 7 band-limited row in polynomial form (logK = log2 of its interval count, nterms = its degree)
     const int kind = i < p->rt->n_small ? 0 : i < p->rt->wide_first ? (rd.logK == 11 ? 2 : 1) : i < p->rt->ols_first ? 3 :

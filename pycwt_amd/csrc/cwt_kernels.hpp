@@ -1198,7 +1198,8 @@ __global__ void k_aols_gtab(const RowDesc* __restrict__ rows, Mother mo, int log
 }
 
 // Spectra of the input blocks of x_M (complex, N-periodic): block b covers x_M[b L - H .. b L - H + P).  One workgroup
-// per block, forward transform as conj(inverse(conj)); all P bins are kept (x_M is not real).
+// per block, forward transform as conj(inverse(conj)); all P bins are kept (x_M is not real).  blockIdx.y = signal of a
+// batch: its x_M at xm + y N, its block spectra at xs + y nblocks (P + 8).
 template <typename T, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_aols_fwd(const cplx<T>* __restrict__ xm, int logN, int halo, const cplx<T>* __restrict__ tw_all,
@@ -1209,6 +1210,7 @@ k_aols_fwd(const cplx<T>* __restrict__ xm, int logN, int halo, const cplx<T>* __
   using F = ct::Fft<T, LOGP, 0, false>;
   const long nmask = (1L << logN) - 1;
   const long first = long(blockIdx.x) * (P - 2 * halo) - halo;
+  xm += long(blockIdx.y) << logN;
   F f;
   f.t = 0;
   f.j = threadIdx.x;
@@ -1219,18 +1221,20 @@ k_aols_fwd(const cplx<T>* __restrict__ xm, int logN, int halo, const cplx<T>* __
     re[e] = v.x; im[e] = -v.y;
   }
   f.run(re, im, lds, tw_all + (P - 2));
-  cplx<T>* out = xs + long(blockIdx.x) * (P + 8);
+  cplx<T>* out = xs + (long(blockIdx.y) * gridDim.x + long(blockIdx.x)) * (P + 8);
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[f.j + e * NT] = mk<T>(re[e], -im[e]);
 }
 
 // The rows: workgroup = (block, row).  The 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of it back to
 // back, so that a block spectrum is fetched into one L2 once.  y = IFFT_P(X_b * table), columns [H, H + L) are stored.
+// blockIdx.y = signal of a batch: its rows at rows + y g.nrows, its block spectra at xs + y nblocks (P + 8); xhat = the
+// spectra of the batch (the Nyquist bin of a row's signal at xhat[rd.spec_off + N / 2], two-sided filters only).
 template <typename T, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64)
                                                                 : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
 k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const T* __restrict__ gtab,
-            const cplx<T>* __restrict__ tw_all, AolsGeom g, const cplx<T>* __restrict__ xhat_nyq, cplx<T>* __restrict__ W,
+            const cplx<T>* __restrict__ tw_all, AolsGeom g, const cplx<T>* __restrict__ xhat, long nyq, cplx<T>* __restrict__ W,
             long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
@@ -1239,9 +1243,9 @@ k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, co
   const unsigned seq = blockIdx.x >> 3;
   const unsigned blk = (seq / unsigned(g.nrows)) * 8u + (blockIdx.x & 7u);
   if (blk >= unsigned(g.nblocks)) return;
-  const RowDesc rd = rows[seq % unsigned(g.nrows)];
+  const RowDesc rd = rows[blockIdx.y * unsigned(g.nrows) + seq % unsigned(g.nrows)];
   const int H = g.halo, L = P - 2 * H;
-  const cplx<T>* xb = xs + long(blk) * (P + 8);
+  const cplx<T>* xb = xs + (long(blockIdx.y) * g.nblocks + long(blk)) * (P + 8);
   const T* gt = gtab + rd.tab_off;
   const long col0 = long(blk) * L, left = ncols - col0;
   const int nlim = left < L ? int(left) : L;
@@ -1266,7 +1270,7 @@ k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, co
       if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
     }
   } else {                                                // two-sided real filter of a real signal (see above)
-    const cplx<T> xn = *xhat_nyq;
+    const cplx<T> xn = xhat[rd.spec_off + nyq];
     const T nr = T(rd.nyq_re) * xn.x - T(rd.nyq_im) * xn.y, ni = T(rd.nyq_re) * xn.y + T(rd.nyq_im) * xn.x;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {

@@ -576,7 +576,8 @@ def test_config4_full_batch_sampled_pairs(hip_library):
     plan.sync()
     classes = plan.row_classes()
     assert len(classes) == nb * rows
-    assert any(c.startswith("ols") for c in classes) and any(c.startswith("two_pass") for c in classes)
+    assert any(c.startswith("ols") for c in classes) and any(c.startswith("aols") for c in classes)
+    assert not any(c.startswith("two_pass") for c in classes)      # (round 3: 9 two-pass rows per signal)
     xhat0 = _download_rows(plan, xh, nb - 1, 1, N, np.complex128)[0]
     ref0 = np.fft.fft(X[nb - 1])
     assert np.abs(xhat0 - ref0).max() < 1e-12 * np.abs(ref0).max()

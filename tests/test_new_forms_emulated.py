@@ -177,3 +177,48 @@ def test_dog_rows_clipped_at_nyquist(emu_library, m_order, prec, logn, n0_off):
     W1, split1, _ = transform(emu_library, N, x, orc.DOG, m_order, sj, prec, opts, with_signal=False)
     assert split1["aols"] == 0 and split1["two_pass"] >= split0["two_pass"]      # (no overlap-save rows either without the signal)
     assert row_errors(W1, ref)[0].max() < bar
+
+
+@pytest.mark.parametrize("kind,param,prec,logn,nb,rows,n0_off,opts", [
+    (orc.MORLET, 6, 64, 16, 4, 48, 0, {}),
+    (orc.MORLET, 6, 64, 15, 8, 40, 777, {"chunk_rows": 3}),     # padded signals; the batch goes through in chunks of 3 signals
+    (orc.PAUL, 4, 32, 15, 8, 40, 1, {}),
+    (orc.DOG, 2, 32, 15, 9, 32, 5, {}),                          # two-sided filter: the Nyquist bin of every signal's own spectrum
+    (orc.DOG, 3, 64, 15, 8, 32, 0, {"chunk_rows": 5}),
+])
+def test_batch_rows_clipped_at_nyquist_on_the_band_passed_signals(emu_library, kind, param, prec, logn, nb, rows, n0_off, opts):
+    """cwt_transform_batch: the rows clipped at the Nyquist bins run as overlap-save rows on every signal's band-passed
+    complex signal (one mask pass and one set of block spectra per signal, one filter table per scale) instead of
+    two-pass rows; every (signal, scale) pair against the oracle and against the same call without the form."""
+    N = 1 << logn
+    n0 = N - n0_off
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    es = np.dtype(real).itemsize
+    X = np.random.default_rng(9).standard_normal((nb, n0)).astype(real)
+    m = orc.Mother(kind, param)
+    sj = grid(N, 1.0, m, rows)
+    nr = len(sj)
+    out = {}
+    for label, extra in (("aols", {}), ("two_pass", {"aols": 0})):
+        plan = _hip.Plan(N, prec, max_rows=nb * nr, lib=emu_library, options=dict(opts, **extra))
+        xd = _hip.DeviceBuffer(X.nbytes, lib=emu_library)
+        xh = _hip.DeviceBuffer(nb * N * 2 * es, lib=emu_library)
+        Wd = _hip.DeviceBuffer(nb * nr * n0 * 2 * es, lib=emu_library)
+        xd.upload(plan, X)
+        plan.transform_batch(xd.ptr, nb, n0, n0, kind, param, 1.0, sj, xh.ptr, Wd.ptr, n0, n0)
+        out[label] = (Wd.download(plan, (nb, nr, n0), cplx), plan.row_classes(), plan.last_split())
+        for b in (xd, xh, Wd):
+            b.free()
+        plan.close()
+    got, labels, split = out["aols"]
+    assert len(labels) == nb * nr and labels[:nr] == labels[-nr:]
+    n_a = sum(l.startswith("aols") for l in labels[:nr])
+    assert n_a >= 3 and split["aols"] == nb * n_a, (labels[:nr], split)
+    assert out["two_pass"][2]["aols"] == 0 and out["two_pass"][2]["two_pass"] >= nb * n_a
+    assert split["two_pass"] == out["two_pass"][2]["two_pass"] - nb * n_a
+    for b in range(nb):
+        ref = orc.cwt_rows(X[b].astype(np.float64), 1.0, sj, m, N=N)[:, :n0]
+        per_row, _ = row_errors(got[b], ref)
+        assert per_row.max() < TOL[prec], (b, per_row.argmax(), per_row.max(), labels[per_row.argmax()])
+        per_row, _ = row_errors(got[b], out["two_pass"][0][b])
+        assert per_row.max() < TOL[prec]
