@@ -16,13 +16,18 @@ for c in c3_paul c3_dog; do
   find $P/trace_ser -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_serialized.csv \;
   find $P -type f -size +8M -delete
 done
-python tools/timeline.py $PWD/gpurun_out/r4final/prof_c2/trace --steps 2 > $OUT/timeline_c2.txt 2>&1
+python tools/timeline.py $PWD/gpurun_out/r4final/prof_c2/trace --steps 2 --steady > $OUT/timeline_c2.txt 2>&1
 # per-rank shares
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-live-traffic > $OUT/shard_all.json 2>/dev/null
 for G in 2 4 8; do for R in $(seq 0 $((G-1))); do
   timeout 120 python bench.py --steps 20 --warmup 3 --shard $R/$G --force-dist --no-cpu-baseline --no-extra --no-live-traffic > $OUT/shard_${G}_$R.json 2>/dev/null
 done; done
+python tools/shard_table.py $OUT > $OUT/shards.txt 2>&1; cat $OUT/shards.txt
+timeout 120 tools/microbench/host_latency 504 97 > $OUT/host_latency_504.txt 2>&1
+timeout 120 tools/microbench/host_latency 4000 60 > $OUT/host_latency_4000.txt 2>&1
+timeout 120 python tests/perf/latency_breakdown.py > $OUT/breakdown.txt 2>&1
 timeout 300 python tests/perf/latency_bench.py > $OUT/latency.txt 2>&1; tail -5 $OUT/latency.txt
+timeout 300 python tests/perf/batch_classes.py 256 > $OUT/batch_classes.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --tol 1e-16,1e-12,1e-10,1e-9,1e-8 > $OUT/tolerance_c2.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --config c3_dog --tol 1e-8,1e-6,3e-5,1e-4 > $OUT/tolerance_dog.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --config c3_paul --tol 1e-8,1e-6,3e-5,1e-4 > $OUT/tolerance_paul.txt 2>&1
