@@ -196,7 +196,6 @@ struct cwt_plan {
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
   int host_direct = 1;     // cwt_execute_host, transforms that fit one workgroup: the kernels read the signal from / write W into page-locked host memory
-  int ols_hold = 0;        // 1 = the overlap-save rows wait for the coefficients of the polynomial rows (tuning; see rows_launch)
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
                            // HIP graph on its second occurrence and replay it from the third on
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
@@ -308,7 +307,7 @@ struct cwt_plan {
   std::vector<Timed> timed;
   std::vector<hipEvent_t> free_events;
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
-  hipEvent_t ev_ols = nullptr, ev_coef = nullptr;
+  hipEvent_t ev_ols = nullptr;
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
   hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
@@ -1738,15 +1737,13 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   // the overlap-save rows.  What starved them in the first build (k_poly_coef 337 us instead of 67, k_poly_rows alone at
   // the end of the step) were the 512-thread / 68-KB workgroups of the 8192-point overlap-save tiles launched first; with
   // the 4096-point tiles first the coefficient workgroups find their slots, and holding the overlap-save rows back until
-  // the coefficients are done (option "ols_hold") only leaves the chip idle: 0.916 against 0.898 ms at config 2.
+  // the coefficients are done only leaves the chip idle: 0.916 against 0.898 ms at config 2 (EXPERIMENTS.md I.4).
   const bool poly_on_side = p->rt->n_poly && side_narrow;
   if (p->rt->n_poly) {
     rc = launch_poly_coef<T>(p, xhat, mo, poly_on_side ? p->side[0] : p->stream, poly_on_side ? p->side2 : nullptr);
     if (rc) return rc;
-    if (poly_on_side) HIPCHECK(hipEventRecord(p->ev_coef, p->side[0]));
   }
   if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
-    if (poly_on_side && p->ols_hold) HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_coef, 0));
     rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1]);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
@@ -1903,21 +1900,10 @@ int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes) {
   return CWT_OK;
 }
 
-// Side streams (band-limited rows, overlap-save chain, K = 2048 rows beside the two-pass chain on the plan's stream) at
-// the default priority: all four queues are served alike.  Rounds 1-2 created them at the lowest priority (filler work
-// under the two-pass chain); at sustained clocks that measured +1 % on the fp64 step (1.005-1.007 against 0.993-0.998 ms,
-// three pairs) and +-0 in fp32.  CWT_SIDE_PRIORITY=low restores it (tuning).
-hipError_t create_side_stream(hipStream_t* s, bool poly = false) {
-  int least = 0, greatest = 0;
-  const char* ep = std::getenv("CWT_POLY_PRIORITY");
-  if (poly && ep && std::string(ep) == "high" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-  const char* e = std::getenv("CWT_SIDE_PRIORITY");
-  if (e && std::string(e) == "low" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
-  (void)hipGetLastError();
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-}
+// Side streams (band-limited rows, overlap-save chain, coefficients of the polynomial rows beside the plan's stream) at the
+// default priority: all queues are served alike.  Rounds 1-2 created them at the lowest priority (+1 % on the fp64 step at
+// sustained clocks); a high priority for the coefficient stream measured +-0 in round 4 (EXPERIMENTS.md).
+hipError_t create_side_stream(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 int grow(void** buf, size_t* have, size_t need, hipStream_t s) {
   if (*have >= need) return CWT_OK;
@@ -1969,14 +1955,13 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
-    if (create_side_stream(&p->side[i], i == 0) != hipSuccess ||
+    if (create_side_stream(&p->side[i]) != hipSuccess ||
         hipEventCreate(&p->ev_a[i]) != hipSuccess || hipEventCreate(&p->ev_b[i]) != hipSuccess)
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
   if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
   if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && hipEventCreate(&p->ev_coef) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && (create_side_stream(&p->side2, true) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
+  if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
@@ -2011,7 +1996,6 @@ int cwt_plan_destroy(cwt_plan* p) {
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
-  if (p->ev_coef) (void)hipEventDestroy(p->ev_coef);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& g : p->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -2076,7 +2060,6 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "narrow_terms") { if (value < 1 || value > 16) return fail(CWT_EINVAL, "narrow_terms in [1,16]"); p->narrow_terms = int(value); }
   else if (k == "ols") p->ols = value != 0;
   else if (k == "graph") p->graph = value != 0;
-  else if (k == "ols_hold") p->ols_hold = value != 0;
   else if (k == "host_direct") p->host_direct = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;

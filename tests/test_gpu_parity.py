@@ -943,14 +943,14 @@ def test_shim_results_live_in_their_own_page_locked_buffers(hip_library):
 
 def test_stream_placement_of_the_signal_path_keeps_every_bit(hip_library):
     """cwt_transform (the call that has the signal: overlap-save, band-passed and polynomial rows on up to five streams):
-    where a launch is queued must not change a bit of W -- the block spectra early or late, the overlap-save rows behind
-    the coefficients or not, everything on the plan's own stream."""
+    where a launch is queued must not change a bit of W -- the block spectra early or late, the polynomial rows beside
+    the others or behind them, everything on the plan's own stream."""
     N = 1 << 20
     x = np.random.default_rng(78).standard_normal(N)
     m = orc.Mother(orc.MORLET, 6)
     sj = grid(N, 1.0, m, 256)[:128:2]                     # 64 rows: overlap-save on both tile sizes, band-passed, polynomial
     base = None
-    for opts in (None, {"ols_early": 0}, {"ols_hold": 1}, {"overlap_narrow": 0, "ols_early": 0, "ols_side": 0}):
+    for opts in (None, {"ols_early": 0}, {"overlap_narrow": 0}, {"overlap_narrow": 0, "ols_early": 0, "ols_side": 0}):
         plan = _hip.Plan(N, 64, max_rows=64, options=dict(opts or {}, tolerance=1e-9))
         xd, xh, Wd = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 16), _hip.DeviceBuffer(len(sj) * N * 16)
         xd.upload(plan, x)
