@@ -2886,7 +2886,8 @@ bool is_pinned(const void* ptr, size_t bytes) {
 int cwt_host_malloc(void** ptr_host, size_t bytes) {
   if (!ptr_host || !bytes) return fail(CWT_EINVAL, "NULL argument or zero size");
   void* q = nullptr;
-  if (hipHostMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(CWT_ENOMEM, "page-locked allocation failed"); }
+  // (portable + mapped: a buffer serves the plans of every device of the process, whichever was current when it was made)
+  if (hipHostMalloc(&q, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return fail(CWT_ENOMEM, "page-locked allocation failed"); }
   { std::lock_guard<std::mutex> lock(g_pinned_mutex); g_pinned[reinterpret_cast<uintptr_t>(q)] = bytes; }
   *ptr_host = q;
   return CWT_OK;

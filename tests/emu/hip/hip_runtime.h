@@ -97,6 +97,7 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
   return posix_memalign(p, 256, n ? n : 256) == 0 ? hipSuccess : hipErrorInvalidValue;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+constexpr unsigned hipHostMallocPortable = 0x1, hipHostMallocMapped = 0x2;
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
