@@ -483,6 +483,40 @@ def config1_latency(calls=300):
             "includes": "host scale grid, H2D of the signal, kernels, D2H of W and the spectrum"}
 
 
+def config5_callers(logn=20, dj=0.25):
+    """BASELINE config 5 without its Monte-Carlo loop, on ONE GPU: pycwt_amd.xwt and pycwt_amd.wct (sig=False) of two
+    N = 2^20 series, NumPy in, NumPy out -- two transforms, the smoothing of wavelet.py:499-514 on the device, and the
+    download of the result matrices, which is most of the time (PCIe).  Parity: tests/test_gpu_parity.py::
+    test_config5_deterministic_part_at_full_size, test_callers_against_reference_fixture."""
+    import pycwt_amd
+    n = 1 << logn
+    rng = np.random.default_rng(55)
+    e = rng.standard_normal(n)
+    y1 = e + np.sin(2 * np.pi * np.arange(n) / 500.0)
+    y2 = 0.5 * np.roll(e, 3) + rng.standard_normal(n) + np.sin(2 * np.pi * np.arange(n) / 500.0 + 0.7)
+
+    def best(f, reps=3):
+        out = f()
+        shape = out[0].shape
+        del out
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = f()
+            ts.append(time.perf_counter() - t0)
+            del out
+        return min(ts) * 1e3, shape
+    try:
+        x_ms, shape = best(lambda: pycwt_amd.xwt(y1, y2, 1.0, dj))
+        w_ms, _ = best(lambda: pycwt_amd.wct(y1, y2, 1.0, dj, sig=False))
+    except Exception as exc:                        # (a box without the memory for the intermediates: report, do not fail the line)
+        return {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
+    return {"workload": f"xwt and wct(sig=False) of two N=2^{logn} series, dj={dj}: {shape[0]} scales, NumPy in / out (BASELINE config 5 "
+                        "without the Monte-Carlo loop, one GPU)", "xwt_ms": x_ms, "wct_ms": w_ms,
+            "xwt_host_GBs": shape[0] * n * 16 / (x_ms * 1e-3) / 1e9,
+            "includes": "two transforms, smoothing, coherence on the device; download of the result matrices (PCIe-bound)"}
+
+
 def config4_batch(rt, steps=3):
     """BASELINE config 4 on ONE GPU at full size: 1024 signals x N = 2^16 x 128 Morlet scales through cwt_transform_batch,
     W (137 GB complex128) device resident.  Roofline: 16 B per sample*scale over the timed step."""
@@ -771,6 +805,7 @@ def main():
                                        "row_split": r["roofline"].get("row_split"), "from_idle": r.get("from_idle")}
         out["extra"]["c1_nino3_latency"] = config1_latency()
         out["extra"]["c4_batch"] = config4_batch(rt)
+        out["extra"]["c5_xwt_wct"] = config5_callers()
         for c in ("c3_paul", "c3_dog"):
             r = measure(rt, c, args, rows_total, {}, want_cpu=True)
             out["extra"][c] = {"workload": f"N=2^{args.logn} {r['label']} {rows_total} scales (BASELINE config 3)",

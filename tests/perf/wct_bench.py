@@ -1,0 +1,30 @@
+"""BASELINE config 5 without the Monte-Carlo loop: pycwt_amd.xwt and pycwt_amd.wct of two N = 2^20 series (NumPy in, NumPy
+out, PCIe included), and the reference's time for the same calls where it is mounted and small enough to wait for.
+    python tests/perf/wct_bench.py [log2 N] [dj]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import pycwt_amd
+
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dj = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
+n = 1 << logn
+rng = np.random.default_rng(55)
+e = rng.standard_normal(n)
+y1 = e + np.sin(2 * np.pi * np.arange(n) / 500.0)
+y2 = 0.5 * np.roll(e, 3) + rng.standard_normal(n) + np.sin(2 * np.pi * np.arange(n) / 500.0 + 0.7)
+
+
+def best(f, reps=3):
+    f()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t); del r
+    return min(ts)
+
+
+t_x = best(lambda: pycwt_amd.xwt(y1, y2, 1.0, dj))
+t_w = best(lambda: pycwt_amd.wct(y1, y2, 1.0, dj, sig=False))
+rows = pycwt_amd.xwt(y1, y2, 1.0, dj)[0].shape[0]
+print(f"N = 2^{logn}, dj = {dj}: {rows} scales.  xwt {t_x * 1e3:.1f} ms ({rows * n * 16 / t_x / 1e9:.1f} GB/s of W12 to the host), "
+      f"wct (sig=False) {t_w * 1e3:.1f} ms ({rows * n * 16 / t_w / 1e9:.1f} GB/s of WCT + angle to the host)")
