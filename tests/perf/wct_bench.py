@@ -28,3 +28,18 @@ t_w = best(lambda: pycwt_amd.wct(y1, y2, 1.0, dj, sig=False))
 rows = pycwt_amd.xwt(y1, y2, 1.0, dj)[0].shape[0]
 print(f"N = 2^{logn}, dj = {dj}: {rows} scales.  xwt {t_x * 1e3:.1f} ms ({rows * n * 16 / t_x / 1e9:.1f} GB/s of W12 to the host), "
       f"wct (sig=False) {t_w * 1e3:.1f} ms ({rows * n * 16 / t_w / 1e9:.1f} GB/s of WCT + angle to the host)")
+
+if len(sys.argv) > 3:                                   # Monte-Carlo significance: draws per second for this scale grid
+    mc = int(sys.argv[3])
+    from pycwt_amd import wavelet as w
+    m = pycwt_amd.Morlet(6)
+    s0 = 2 * 1.0 / m.flambda()
+    J = int(np.round(np.log2(n * 1.0 / s0) / dj))
+    N, sj, *_ = w._mc_setup(m, 1.0, dj, s0, J)
+    np.random.seed(3)
+    pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=2, progress=False, cache=False)      # plans, tables
+    t = time.perf_counter()
+    pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=mc, progress=False, cache=False)
+    t = time.perf_counter() - t
+    print(f"wct_significance for that grid: surrogates of {N} samples x {len(sj)} scales, {mc} draws in {t:.2f} s = "
+          f"{t / mc * 1e3:.1f} ms per draw (the reference's default 300 draws: {t / mc * 300:.0f} s on one GPU)")
