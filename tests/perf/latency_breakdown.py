@@ -29,3 +29,13 @@ stub = min(per_call(f, 2000) for _ in range(3))
 plan.lib.cwt_execute_host = real
 print(f"pycwt_amd.cwt 504 x {sj.size}: {whole:.1f} us per call; Plan.execute_host alone {inner:.1f} us; "
       f"Python with the C call stubbed {stub:.1f} us")
+
+# the inverse of the same call (host W in, host vector out), next to the reference's NumPy expression (wavelet.py:169-170)
+W, sj = pycwt_amd.cwt(x, 0.25, 1 / 12, wavelet="morlet")[:2]
+g = lambda: pycwt_amd.icwt(W, sj, 0.25, 1 / 12, "morlet")
+for _ in range(10):
+    g()
+inv = min(per_call(g, 300) for _ in range(3))
+ref = lambda: (1 / 12 * np.sqrt(0.25) / (0.776 * np.pi ** -0.25)) * (np.real(W) / (np.ones([1, W.shape[1]]) * sj[:, None]) ** 0.5).sum(axis=0)
+cpu = min(per_call(ref, 300) for _ in range(3))
+print(f"pycwt_amd.icwt {W.shape[0]} x {W.shape[1]}: {inv:.1f} us per call; the reference's NumPy expression on this host: {cpu:.1f} us")
