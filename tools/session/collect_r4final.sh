@@ -32,4 +32,7 @@ cat $S/tolerance_c2.txt $S/tolerance_dog.txt $S/tolerance_paul.txt | grep -v amd
   echo "# the plan's own HIP-event timers (option profile).  Round 3 / start of round 4: 8.61 ms per call, 9 two-pass rows per"
   echo "# signal at 1.49 ms (1.6 TB/s); now those rows run on the band-passed signals (aols + aols_pre)."
   grep -v amdgpu.ids $S/batch_classes.txt; } > $P/r04_batch_classes.txt
+{ echo "# BASELINE config 5 on ONE GPU (tests/perf/wct_bench.py 20 0.25 30; NumPy in, NumPy out; round 4)"
+  grep -v amdgpu.ids $S/wct.txt; echo
+  sed -n '/^# Before/,$p' $P/r04_wct.txt; } > /tmp/r04_wct.txt && mv /tmp/r04_wct.txt $P/r04_wct.txt
 ls -la $P | grep r04 | wc -l

@@ -28,6 +28,7 @@ timeout 120 tools/microbench/host_latency 4000 60 > $OUT/host_latency_4000.txt 2
 timeout 120 python tests/perf/latency_breakdown.py > $OUT/breakdown.txt 2>&1
 timeout 300 python tests/perf/latency_bench.py > $OUT/latency.txt 2>&1; tail -5 $OUT/latency.txt
 timeout 300 python tests/perf/batch_classes.py 256 > $OUT/batch_classes.txt 2>&1
+timeout 600 python tests/perf/wct_bench.py 20 0.25 30 > $OUT/wct.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --tol 1e-16,1e-12,1e-10,1e-9,1e-8 > $OUT/tolerance_c2.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --config c3_dog --tol 1e-8,1e-6,3e-5,1e-4 > $OUT/tolerance_dog.txt 2>&1
 timeout 600 python tests/perf/tolerance_sweep.py --config c3_paul --tol 1e-8,1e-6,3e-5,1e-4 > $OUT/tolerance_paul.txt 2>&1
