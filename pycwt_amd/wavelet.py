@@ -218,7 +218,7 @@ def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
             key = (type(mother), mother.device_id(), n0, dt, dj, s0, J, pad)
             hit = _geometry_cache.get(key)
             if hit is not None:
-                return hit
+                return hit[0]
         except TypeError:                                   # an unhashable argument (array-valued dt ...): no cache
             key = None
     sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
@@ -229,9 +229,11 @@ def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
     ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)              # wavelet.py:94
     geo = (N, sj, freqs, _coi(mother, n0, dt), ftfreqs[1:N // 2] / (2 * np.pi), bad)
     if key is not None:
-        if len(_geometry_cache) >= 64:
+        nbytes = sum(a.nbytes for a in geo[1:] if isinstance(a, np.ndarray))
+        held = sum(v[1] for v in _geometry_cache.values())
+        if len(_geometry_cache) >= 64 or held + nbytes > (128 << 20):      # (a 2^20-point call keeps 12 MB here)
             _geometry_cache.clear()
-        _geometry_cache[key] = geo
+        _geometry_cache[key] = (geo, nbytes)
     return geo
 
 
@@ -419,12 +421,11 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     n0 = len(signal)
-    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
-    N = _next_pow2(n0)
-    bad = _nan_rows(mother, sj, N, dt)
-    if bad.any() and not bad.all() and np.isfinite(np.asarray(signal, dtype=np.float64)).all():   # see cwt()
-        sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
     kind, param = _device_id(mother)
+    user_freqs = freqs is not None
+    N, sj, freqs, coi, fftfreqs, bad = _geometry(mother, n0, dt, dj, s0, J, freqs, True)
+    if bad is not None and not bad.all() and np.isfinite(np.asarray(signal, dtype=np.float64)).all():   # see cwt()
+        sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
     plan = _plan(N, precision, device, sj.size)
     es = np.dtype(plan.real).itemsize
     xd, xh = _hip.DeviceBuffer(n0 * es, device), _hip.DeviceBuffer(N * 2 * es, device)
@@ -441,9 +442,9 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     finally:
         xd.free()
         xh.free()
-    coi = _coi(mother, n0, dt)
-    ftfreqs = 2 * np.pi * np.fft.fftfreq(N, dt)
-    return DeviceTransform(plan, Wd, sj, freqs, coi, xhat[1:N // 2] / N ** 0.5, ftfreqs[1:N // 2] / (2 * np.pi),
+    if not user_freqs:
+        freqs = np.array(freqs)                 # (cached grids stay private, as in cwt())
+    return DeviceTransform(plan, Wd, np.array(sj), freqs, np.array(coi), xhat[1:N // 2] / N ** 0.5, np.array(fftfreqs),
                            mother, dt, n0)
 
 
