@@ -2105,15 +2105,19 @@ int cwt_spectrum_range(cwt_plan* p, const void* xhat_dev, int64_t n, double* max
   if (!p || !xhat_dev || !max_abs || !rms_abs || !floor_abs) return fail(CWT_EINVAL, "NULL argument");
   if (n < 1) return fail(CWT_EINVAL, "n must be >= 1");
   HIPCHECK(hipSetDevice(p->device));
-  constexpr int kOut = 2 + SPECTRUM_OCTAVES;
-  if (!p->range_dev && hipMalloc(reinterpret_cast<void**>(&p->range_dev), kOut * sizeof(double)) != hipSuccess)
+  constexpr int kOut = SPECTRUM_SLOTS, kGroupsMax = 512;
+  if (!p->range_dev && hipMalloc(reinterpret_cast<void**>(&p->range_dev), size_t(kGroupsMax + 1) * kOut * sizeof(double)) != hipSuccess)
     return fail(CWT_ENOMEM, "device allocation failed");
+  // slices of at least 4096 bins, at most two workgroups per CU
+  const int groups = int(std::max<int64_t>(1, std::min<int64_t>(kGroupsMax, n / 4096)));
+  double* part = p->range_dev + kOut;
   if (p->prec == 64)
-    hipLaunchKernelGGL((k_spectrum_range<double>), dim3(1), dim3(1024), 1024 * sizeof(double), p->stream,
-                       static_cast<const double2*>(xhat_dev), long(n), p->range_dev);
+    hipLaunchKernelGGL((k_spectrum_range<double>), dim3(groups), dim3(256), (256 + kOut + 2) * sizeof(double), p->stream,
+                       static_cast<const double2*>(xhat_dev), long(n), part);
   else
-    hipLaunchKernelGGL((k_spectrum_range<float>), dim3(1), dim3(1024), 1024 * sizeof(double), p->stream,
-                       static_cast<const float2*>(xhat_dev), long(n), p->range_dev);
+    hipLaunchKernelGGL((k_spectrum_range<float>), dim3(groups), dim3(256), (256 + kOut + 2) * sizeof(double), p->stream,
+                       static_cast<const float2*>(xhat_dev), long(n), part);
+  hipLaunchKernelGGL(k_spectrum_fold, dim3(1), dim3(64), 0, p->stream, part, groups, p->range_dev);
   HIPCHECK(hipGetLastError());
   double h[kOut] = {0};
   HIPCHECK(hipMemcpyAsync(h, p->range_dev, sizeof(h), hipMemcpyDeviceToHost, p->stream));

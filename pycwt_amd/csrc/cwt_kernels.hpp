@@ -1700,40 +1700,80 @@ __global__ void k_coherence_hist(const T* __restrict__ R2, long ld, const long* 
 }
 
 // k_spectrum_range: out[0] = max_k |xhat[k]|^2, out[1] = sum_k |xhat[k]|^2 over the n bins, out[2 + b] = the sum over the
-// octave b of the positive half, 2^b <= k < min(2^(b+1), n/2) (one workgroup, fp64 accumulation): the dynamic range of the
-// spectrum, by which a caller divides the accuracy it wants (cwt_spectrum_range).
+// octave b of the positive half, 2^b <= k < min(2^(b+1), n/2): the dynamic range of the spectrum, by which a caller divides
+// the accuracy it wants (cwt_spectrum_range).  Two launches: every workgroup reduces a contiguous slice (fp64 accumulation; a
+// slice touches few octaves, found by the leading-zero count of the bin) into part[workgroup][2 + OCTAVES]; one workgroup
+// folds those.  (One workgroup for the whole spectrum, as at first, read 134 MB in 2.5 ms at N = 2^23.)
 constexpr int SPECTRUM_OCTAVES = 32;
+constexpr int SPECTRUM_SLOTS = 2 + SPECTRUM_OCTAVES;
 template <typename T>
-__global__ void k_spectrum_range(const cplx<T>* __restrict__ xhat, long n, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_spectrum_range(const cplx<T>* __restrict__ xhat, long n, double* __restrict__ part) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
-  double* part = reinterpret_cast<double*>(lds_raw);       // [0, bd): scratch of one reduction
-  double mx = 0, sm = 0, oct[SPECTRUM_OCTAVES];
-  for (int b = 0; b < SPECTRUM_OCTAVES; ++b) oct[b] = 0;
-  for (long k = threadIdx.x; k < n; k += blockDim.x) {
-    const cplx<T> v = xhat[k];
-    const double a = double(v.x) * double(v.x) + double(v.y) * double(v.y);
-    mx = a > mx || a != a ? a : mx;                         // NaN propagates
-    sm += a;
-    if (k >= 1 && k < n / 2) {
-      int b = 0;
-      while ((2L << b) <= k) ++b;                           // floor(log2 k)
-      oct[b] += a;
+  double* red = reinterpret_cast<double*>(lds_raw);        // 256 doubles of reduction scratch + the workgroup's slots
+  double* acc = red + 256;
+  if (threadIdx.x < SPECTRUM_SLOTS) acc[threadIdx.x] = 0;
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long k0 = long(blockIdx.x) * per, k1 = k0 + per < n ? k0 + per : n;
+  // octaves this slice can touch: [b_lo, b_hi]
+  const int b_lo = k0 < 1 ? 0 : 63 - __builtin_clzll((unsigned long long)k0);
+  const int b_hi = k1 < 2 ? 0 : 63 - __builtin_clzll((unsigned long long)(k1 - 1));
+  double mx = 0, sm = 0;
+  __syncthreads();
+  for (int b = b_lo; b <= b_hi && b < SPECTRUM_OCTAVES; ++b) {
+    long lo = 1L << b, hi = 2L << b;
+    if (hi > n / 2) hi = n / 2;
+    if (lo < k0) lo = k0;
+    if (hi > k1) hi = k1;
+    double o = 0;
+    for (long k = lo + threadIdx.x; k < hi; k += 256) {
+      const cplx<T> v = xhat[k];
+      o += double(v.x) * double(v.x) + double(v.y) * double(v.y);
     }
-  }
-  for (int q = 0; q < 2 + SPECTRUM_OCTAVES; ++q) {
-    part[threadIdx.x] = q == 0 ? mx : q == 1 ? sm : oct[q - 2];
+    red[threadIdx.x] = o;
     __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-      if (int(threadIdx.x) < s) {
-        const double o = part[threadIdx.x + s];
-        if (q == 0) { if (o > part[threadIdx.x] || o != o) part[threadIdx.x] = o; }
-        else part[threadIdx.x] += o;
-      }
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (int(threadIdx.x) < s2) red[threadIdx.x] += red[threadIdx.x + s2];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[q] = part[0];
+    if (threadIdx.x == 0) acc[2 + b] = red[0];
     __syncthreads();
   }
+  for (long k = k0 + threadIdx.x; k < k1; k += 256) {          // (a second pass over the slice: it sits in the L2 now)
+    const cplx<T> v = xhat[k];
+    const double a = double(v.x) * double(v.x) + double(v.y) * double(v.y);
+    mx = a > mx || a != a ? a : mx;                             // NaN propagates
+    sm += a;
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (int(threadIdx.x) < s2) { const double o = red[threadIdx.x + s2]; if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] = red[0];
+  __syncthreads();
+  red[threadIdx.x] = sm;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (int(threadIdx.x) < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[1] = red[0];
+  __syncthreads();
+  if (threadIdx.x < SPECTRUM_SLOTS) part[long(blockIdx.x) * SPECTRUM_SLOTS + threadIdx.x] = acc[threadIdx.x];
+}
+
+// out[q] = fold of part[g][q] over the g workgroups of k_spectrum_range (max for q = 0, sums otherwise); one workgroup.
+__global__ void __launch_bounds__(64) k_spectrum_fold(const double* __restrict__ part, int groups, double* __restrict__ out) {
+  const int q = threadIdx.x;
+  if (q >= SPECTRUM_SLOTS) return;
+  double r = 0;
+  for (int g = 0; g < groups; ++g) {
+    const double o = part[long(g) * SPECTRUM_SLOTS + q];
+    if (q == 0) { if (o > r || o != o) r = o; }
+    else r += o;
+  }
+  out[q] = r;
 }
 
 // k_time_mean: out[j] = (1/ncols) sum_n |W[j, n]|^2  -- the global wavelet spectrum (power.mean(axis=1),

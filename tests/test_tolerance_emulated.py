@@ -136,3 +136,30 @@ def test_largest_scales_keep_their_few_bins(emu_library, monkeypatch, kind, para
     W, _ = run(emu_library, kind, param, prec, tol, sj, x)
     per_row, _ = row_errors(W[keep], ref[keep])
     assert per_row.max() < tol + (1e-13 if prec == 64 else 2e-5), per_row
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+@pytest.mark.parametrize("n", [1, 16, 300, 4096, 5000, 65536, 100001])
+def test_spectrum_range_against_numpy(emu_library, prec, n):
+    """cwt_spectrum_range (a two-stage reduction over slices of the spectrum): largest bin, rms, and the rms of the quietest
+    octave of the positive half with at least 64 bins."""
+    cplx = np.complex128 if prec == 64 else np.complex64
+    rng = np.random.default_rng(n)
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.exp(-np.arange(n) / max(n / 6, 1.0))     # a sloping spectrum
+    z = z.astype(cplx)
+    plan = _hip.Plan(1 << 17, prec, max_rows=4, lib=emu_library)
+    buf = _hip.DeviceBuffer(max(z.nbytes, 16), lib=emu_library)
+    buf.upload(plan, z)
+    mx, rms, floor = plan.spectrum_range(buf.ptr, n)
+    a = np.abs(z.astype(np.complex128))
+    assert mx == pytest.approx(a.max(), rel=1e-12)
+    assert rms == pytest.approx(np.sqrt((a ** 2).mean()), rel=1e-12)
+    octaves = [np.sqrt((a[lo:min(2 * lo, n // 2)] ** 2).mean()) for lo in (1 << b for b in range(6, 32))
+               if min(2 * lo, n // 2) - lo >= 64]
+    assert floor == pytest.approx(min(octaves) if octaves else np.sqrt((a ** 2).mean()), rel=1e-12)
+    z[n // 3] = np.nan                                       # a NaN bin poisons the maximum (and the sums)
+    buf.upload(plan, z)
+    mx, rms, floor = plan.spectrum_range(buf.ptr, n)
+    assert np.isnan(mx) and np.isnan(rms)
+    buf.free()
+    plan.close()
