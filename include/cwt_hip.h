@@ -70,6 +70,7 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "poly_degree"  preferred largest degree of those rows (default 8): a row gets the smallest interval count K' (a power
  *                  of two >= its support, >= 256, <= nfft / 64) whose degree does not exceed it
  *   "poly_min_logn" log2 of the shortest transform that uses the form (default 16)
+ *   "poly_max_logk" log2 of the largest interval count K' (8 ... 14, default 14 = the largest coefficient tile)
  *   "aols"         0 = rows clipped at the Nyquist bins stay two-pass rows (default 1: overlap-save rows on the band-passed
  *                  complex signal, k_aols_*; Morlet, Paul, and -- with the real signal at hand -- DOG of order >= 1)
  *   "aols_min_rows" ... if at least this many rows qualify (default 3: the band-passed signal costs about one two-pass row)
@@ -110,6 +111,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "host_direct"  0 = cwt_execute_host stages transforms that fit one workgroup per row through device buffers and copy
  *                  operations like the longer ones (default 1: their kernels read the signal from and write W into
  *                  page-locked host memory themselves)
+ *   "graph"        1 = repeated cwt_transform calls with the same buffers and scale grid are captured into a HIP graph
+ *                  and replayed (default 0: measured +-0.5 % on the step, the chain is latency bound, not launch bound)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
  *   "profile"      1 = time every kernel class with HIP events (cwt_plan_timings) */
 int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
