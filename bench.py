@@ -612,7 +612,7 @@ def live_traffic(config, logn, rows, n_poly, csize):
                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-prime", "--no-live-traffic",
                    "--opt", "overlap_narrow=0", "--opt", "ols_early=0", "--opt", "ols_side=0"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
