@@ -47,6 +47,9 @@ CONFIGS = {
     "c2": (0, 6.0, 64, "fp64 Morlet(6)"),
     "c3_paul": (1, 4.0, 32, "fp32 Paul(4)"),
     "c3_dog": (2, 2.0, 32, "fp32 DOG(2)"),
+    # not BASELINE configs: the other mothers in double precision (python bench.py --config paul64 / dog64)
+    "paul64": (1, 4.0, 64, "fp64 Paul(4)"),
+    "dog64": (2, 2.0, 64, "fp64 DOG(2)"),
 }
 PARITY_TOL = {64: 1e-8, 32: 1e-5}       # per-row max|dW|/max|W|: 1/100 of north_star's bars (1e-6 / 1e-3)
 # Accuracy target of the timed plans (cwt_plan_set_tolerance).  The engine's own default is round-off (1e-16 / 1e-7: safe

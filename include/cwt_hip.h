@@ -70,6 +70,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "poly_degree"  preferred largest degree of those rows (default 8): a row gets the smallest interval count K' (a power
  *                  of two >= its support, >= 256, <= nfft / 64) whose degree does not exceed it
  *   "poly_min_logn" log2 of the shortest transform that uses the form (default 16)
+ *   "poly_chunk_mb" the polynomial rows go through in as few chunks of about equal coefficient volume as keep that volume
+ *                  below this many MiB (default 96; 0 = all rows at once): planes computed, then consumed while they still sit
+ *                  in the Infinity Cache (matters from ~150 MB: fp64 Paul, round-off targets)
  *   "poly_max_logk" log2 of the largest interval count K' (8 ... 14, default 14 = the largest coefficient tile)
  *   "aols"         0 = rows clipped at the Nyquist bins stay two-pass rows (default 1: overlap-save rows on the band-passed
  *                  complex signal, k_aols_*; Morlet, Paul, and -- with the real signal at hand -- DOG of order >= 1)

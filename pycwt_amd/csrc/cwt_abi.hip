@@ -195,6 +195,7 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
+  int poly_chunk_mb = 96;  // coefficient planes computed and consumed per chunk of polynomial rows (MiB; 0 = all rows at once)
   int host_direct = 1;     // cwt_execute_host, transforms that fit one workgroup: the kernels read the signal from / write W into page-locked host memory
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
                            // HIP graph on its second occurrence and replay it from the third on
@@ -272,10 +273,16 @@ struct cwt_plan {
     // table entry at aux_first is the pseudo-row whose "filter" is the mask (profile 1 on the bins [k_s, N/2))
     // band-limited rows in polynomial form (at the end of the table), grouped by K'
     int n_poly = 0, poly_first = 0;
-    PolyClasses poly_cls{};
-    long poly_wgs[3] = {0, 0, 0};         // workgroups of the k_poly_coef launches on 4096- / 8192- / 16384-point tiles
+    // ... in chunks of bounded coefficient volume (largest K' first): the planes of a chunk are computed, then consumed by
+    // k_poly_rows while they still sit in the Infinity Cache -- with all rows' planes (80 - 300 MB) computed first the
+    // coefficient fetches of the streaming kernel come from HBM and it loses 10 - 40 % (tests/perf/poly_chunks.py)
+    struct PolyChunk {
+      int row_first = 0, nrows = 0, max_logk = 8;   // rows relative to poly_first
+      PolyClasses cls{};                            // (row_first of a class relative to the chunk)
+      long wgs[3] = {0, 0, 0};                      // workgroups of the k_poly_coef launches on 4096- / 8192- / 16384-point tiles
+    };
+    std::vector<PolyChunk> poly_chunks;
     long poly_coef_elems = 0, poly_band_elems = 0;
-    int poly_max_logk = 8;
     int n_aols = 0, aols_first = 0, aux_first = -1, aols_logp = 12;
     int aols_nbatch = 1;                 // signals of a batched call: aols_geom.nrows rows and one mask pseudo-row (aux_first + b) each
     AolsGeom aols_geom{};
@@ -1129,39 +1136,57 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   // polynomial rows: by K', then by degree; coefficient offsets; the workgroups of k_poly_coef per class
   p->rt->poly_first = int(p->rt->table.size());
   p->rt->n_poly = int(poly_rows.size());
-  p->rt->poly_cls.n = 0;
-  p->rt->poly_wgs[0] = p->rt->poly_wgs[1] = p->rt->poly_wgs[2] = 0;
+  p->rt->poly_chunks.clear();
   p->rt->poly_coef_elems = 0;
   if (!poly_rows.empty()) {
+    // largest K' first (their planes are the bulk and their k_poly_coef tiles the slowest to get going), then by degree
     std::stable_sort(poly_rows.begin(), poly_rows.end(), [](const RowDesc& x, const RowDesc& y) {
-      return x.logK != y.logK ? x.logK < y.logK : x.nterms < y.nterms;
+      return x.logK != y.logK ? x.logK > y.logK : x.nterms < y.nterms;
     });
+    const size_t esz = p->esize() * 2;
+    size_t cap = ~size_t(0);
+    if (p->poly_chunk_mb > 0) {                             // as few chunks as the limit allows, of about equal volume
+      size_t total = 0;
+      for (const RowDesc& r : poly_rows) total += (size_t(r.nterms) + 1) * (size_t(1) << r.logK) * esz;
+      const size_t limit = size_t(p->poly_chunk_mb) << 20, n = (total + limit - 1) / limit;
+      cap = n > 1 ? (total + n - 1) / n : ~size_t(0);
+    }
     long off = 0, boff = 0;
-    p->rt->poly_max_logk = 8;
+    size_t vol = 0;
     for (size_t i = 0; i < poly_rows.size(); ++i) {
       RowDesc& r = poly_rows[i];
       r.tab_off = off;                                      // planes: (D + 1) K' complex
       off += (long(r.nterms) + 1) << r.logK;
       r.aux_off = boff;                                     // band: K' complex
       boff += 1L << r.logK;
-      p->rt->poly_max_logk = std::max(p->rt->poly_max_logk, r.logK);
-      PolyClasses& pc = p->rt->poly_cls;
+      const size_t bytes = (size_t(r.nterms) + 1) * (size_t(1) << r.logK) * esz;
+      if (p->rt->poly_chunks.empty() || vol + bytes / 2 > cap) {
+        p->rt->poly_chunks.emplace_back();
+        p->rt->poly_chunks.back().row_first = int(i);
+        vol = 0;
+      }
+      vol += bytes;
+      auto& ch = p->rt->poly_chunks.back();
+      ch.nrows++;
+      ch.max_logk = std::max(ch.max_logk, r.logK);
+      PolyClasses& pc = ch.cls;
       if (pc.n == 0 || pc.c[pc.n - 1].logK != r.logK) {
         if (pc.n == POLY_MAX_CLASSES) return fail(CWT_EINVAL, "too many polynomial-row classes");
-        pc.c[pc.n++] = PolyClass{r.logK, int(i), 0, 0, 0};
+        pc.c[pc.n++] = PolyClass{r.logK, int(i) - ch.row_first, 0, 0, 0};
       }
       PolyClass& c = pc.c[pc.n - 1];
       c.nrows++;
       c.ndeg = std::max(c.ndeg, r.nterms + 1);
     }
-    for (int i = 0; i < p->rt->poly_cls.n; ++i) {         // per tile size (launch): classes in table order
-      PolyClass& c = p->rt->poly_cls.c[i];
-      const int tile = std::max(12, c.logK);                // log2 of the workgroup tile
-      const long tb = 1L << (tile - c.logK);
-      long& wg = p->rt->poly_wgs[tile - 12];
-      c.wg_first = int(wg);
-      wg += (long(c.nrows) * c.ndeg + tb - 1) / tb;
-    }
+    for (auto& ch : p->rt->poly_chunks)
+      for (int i = 0; i < ch.cls.n; ++i) {                  // per tile size (launch): classes in table order
+        PolyClass& c = ch.cls.c[i];
+        const int tile = std::max(12, c.logK);                // log2 of the workgroup tile
+        const long tb = 1L << (tile - c.logK);
+        long& wg = ch.wgs[tile - 12];
+        c.wg_first = int(wg);
+        wg += (long(c.nrows) * c.ndeg + tb - 1) / tb;
+      }
     p->rt->poly_coef_elems = off;
     p->rt->poly_band_elems = boff;
     p->rt->table.insert(p->rt->table.end(), poly_rows.begin(), poly_rows.end());
@@ -1598,58 +1623,60 @@ int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int6
 // st2 != nullptr: the 8192- and 4096-point tiles on that second stream beside the 16384-point ones (three independent,
 // latency-bound launches of one round of workgroups each: 30 + 19 + 20 us back to back), joined into st again.
 template <typename T>
-int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, hipStream_t st, hipStream_t st2 = nullptr) {
+int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, int chunk, hipStream_t st, hipStream_t st2 = nullptr) {
   const cwt_plan::RowTable* rt = p->rt;
+  const auto& ch = rt->poly_chunks[size_t(chunk)];
   int rc = grow(&p->pcoef, &p->pcoef_bytes, size_t(rt->poly_coef_elems) * sizeof(cplx<T>), st);
   if (!rc) rc = grow(&p->pband, &p->pband_bytes, size_t(rt->poly_band_elems) * sizeof(cplx<T>), st);
   if (rc) return rc;
   static const bool once = (allow_big_lds(&k_poly_coef<T, 13>), allow_big_lds(&k_poly_coef<T, 14>), true);
   (void)once;
-  const RowDesc* rows = rt->rows_dev + rt->poly_first;
+  const RowDesc* rows = rt->rows_dev + rt->poly_first + ch.row_first;
   cplx<T>* coef = static_cast<cplx<T>*>(p->pcoef);
   cplx<T>* band = static_cast<cplx<T>*>(p->pband);
   rc = timed_launch(p, KC_POLY_COEF, [&] {
-    for (int r0 = 0; r0 < rt->n_poly; r0 += kMaxGridY)
-      hipLaunchKernelGGL((k_poly_band<T>), dim3(1u << (rt->poly_max_logk - 8), std::min(kMaxGridY, rt->n_poly - r0)), dim3(256), 0, st,
+    for (int r0 = 0; r0 < ch.nrows; r0 += kMaxGridY)
+      hipLaunchKernelGGL((k_poly_band<T>), dim3(1u << (ch.max_logk - 8), std::min(kMaxGridY, ch.nrows - r0)), dim3(256), 0, st,
                          xhat, rows + r0, mo, twn_of<T>(p), p->logN, band);
   }, st);
   if (rc) return rc;
   // largest tiles first: the 16384-point workgroups take a whole CU each and should find the chip as empty as it gets
   const cplx<T>* tw = static_cast<const cplx<T>*>(p->tw_all);
   auto lds_of = [](int lp) { return ((size_t(1) << lp) + (size_t(1) << (lp - 4))) * sizeof(T); };
-  const bool split = st2 && rt->poly_wgs[2] && (rt->poly_wgs[1] || rt->poly_wgs[0]);
+  const bool split = st2 && ch.wgs[2] && (ch.wgs[1] || ch.wgs[0]);
   hipStream_t s2 = split ? st2 : st;
   if (split) {
     HIPCHECK(hipEventRecord(p->ev_big, st));             // the bands are ready
     HIPCHECK(hipStreamWaitEvent(st2, p->ev_big, 0));
   }
-  if (!rc && rt->poly_wgs[2]) rc = timed_launch(p, KC_POLY_COEF, [&] {
-    hipLaunchKernelGGL((k_poly_coef<T, 14>), dim3(unsigned(rt->poly_wgs[2])), dim3(1024), lds_of(14), st,
-                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, st);
-  if (!rc && rt->poly_wgs[1]) rc = timed_launch(p, KC_POLY_COEF, [&] {
-    hipLaunchKernelGGL((k_poly_coef<T, 13>), dim3(unsigned(rt->poly_wgs[1])), dim3(512), lds_of(13), s2,
-                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, s2);
-  if (!rc && rt->poly_wgs[0]) rc = timed_launch(p, KC_POLY_COEF, [&] {
-    hipLaunchKernelGGL((k_poly_coef<T, 12>), dim3(unsigned(rt->poly_wgs[0])), dim3(256), lds_of(12), s2,
-                       static_cast<const cplx<T>*>(band), rows, tw, rt->poly_cls, coef); }, s2);
+  if (!rc && ch.wgs[2]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 14>), dim3(unsigned(ch.wgs[2])), dim3(1024), lds_of(14), st,
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, st);
+  if (!rc && ch.wgs[1]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 13>), dim3(unsigned(ch.wgs[1])), dim3(512), lds_of(13), s2,
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, s2);
+  if (!rc && ch.wgs[0]) rc = timed_launch(p, KC_POLY_COEF, [&] {
+    hipLaunchKernelGGL((k_poly_coef<T, 12>), dim3(unsigned(ch.wgs[0])), dim3(256), lds_of(12), s2,
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, s2);
   if (!rc && split) {
     HIPCHECK(hipEventRecord(p->ev_big, st2));
     HIPCHECK(hipStreamWaitEvent(st, p->ev_big, 0));
   }
   return rc;
 }
-// ... then the streaming kernel (k_poly_rows)
+// ... then the streaming kernel (k_poly_rows) over the rows of the chunk
 template <typename T>
-int launch_poly_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_poly_rows(cwt_plan* p, int chunk, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
-  const RowDesc* rows = rt->rows_dev + rt->poly_first;
+  const auto& ch = rt->poly_chunks[size_t(chunk)];
+  const RowDesc* rows = rt->rows_dev + rt->poly_first + ch.row_first;
   const cplx<T>* coef = static_cast<const cplx<T>*>(p->pcoef);
   const int64_t per_wg = 256 * (sizeof(T) == 8 ? 1 : 2) * POLY_PASSES;
   // LDS: the coefficient sets of the intervals one workgroup touches (shortest interval 2^POLY_MIN_LOGR samples)
   const size_t lds2 = size_t((per_wg >> POLY_MIN_LOGR) + 2) * (POLY_MAX_DEGREE + 1) * sizeof(cplx<T>);
   return timed_launch(p, KC_POLY, [&] {
-    for (int r0 = 0; r0 < rt->n_poly; r0 += kMaxGridY)
-      hipLaunchKernelGGL((k_poly_rows<T>), dim3(unsigned((ncols + per_wg - 1) / per_wg), std::min(kMaxGridY, rt->n_poly - r0)),
+    for (int r0 = 0; r0 < ch.nrows; r0 += kMaxGridY)
+      hipLaunchKernelGGL((k_poly_rows<T>), dim3(unsigned((ncols + per_wg - 1) / per_wg), std::min(kMaxGridY, ch.nrows - r0)),
                          dim3(256), lds2, st, rows + r0, coef, twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
   }, st);
 }
@@ -1740,7 +1767,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   // the coefficients are done only leaves the chip idle: 0.916 against 0.898 ms at config 2 (EXPERIMENTS.md I.4).
   const bool poly_on_side = p->rt->n_poly && side_narrow;
   if (p->rt->n_poly) {
-    rc = launch_poly_coef<T>(p, xhat, mo, poly_on_side ? p->side[0] : p->stream, poly_on_side ? p->side2 : nullptr);
+    rc = launch_poly_coef<T>(p, xhat, mo, 0, poly_on_side ? p->side[0] : p->stream, poly_on_side ? p->side2 : nullptr);
     if (rc) return rc;
   }
   if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
@@ -1790,7 +1817,12 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
   bool narrow_on_side = false;
   if (p->rt->n_poly) {                 // second half, on the same stream as the first (joined below when that is a side stream)
     narrow_on_side = poly_on_side;
-    rc = launch_poly_rows<T>(p, W, ldw, ncols, poly_on_side ? p->side[0] : p->stream);
+    hipStream_t ps = poly_on_side ? p->side[0] : p->stream;
+    const int nchunks = int(p->rt->poly_chunks.size());
+    for (int c = 0; c < nchunks && !rc; ++c) {             // chunk c's rows, then chunk c + 1's coefficients, on one stream
+      rc = launch_poly_rows<T>(p, c, W, ldw, ncols, ps);
+      if (!rc && c + 1 < nchunks) rc = launch_poly_coef<T>(p, xhat, mo, c + 1, ps, poly_on_side ? p->side2 : nullptr);
+    }
     if (rc) return rc;
     if (narrow_on_side) HIPCHECK(hipEventRecord(p->ev_a[0], p->side[0]));
   }
@@ -2064,6 +2096,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "aols") p->aols = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
+  else if (k == "poly_chunk_mb") { if (value < 0 || value > 4096) return fail(CWT_EINVAL, "poly_chunk_mb in [0, 4096] (0 = one chunk)"); p->poly_chunk_mb = int(value); }
   else if (k == "poly_max_logk") { if (value < 8 || value > 14) return fail(CWT_EINVAL, "poly_max_logk in [8, 14]"); p->poly_max_logk = int(value); }
   else if (k == "poly_min_logn") { if (value < 14 || value > 24) return fail(CWT_EINVAL, "poly_min_logn in [14, 24]"); p->poly_min_logn = int(value); }
   else if (k == "aols_min_rows") { if (value < 1 || value > 65536) return fail(CWT_EINVAL, "aols_min_rows >= 1"); p->aols_min_rows = int(value); }

@@ -222,3 +222,21 @@ def test_batch_rows_clipped_at_nyquist_on_the_band_passed_signals(emu_library, k
         assert per_row.max() < TOL[prec], (b, per_row.argmax(), per_row.max(), labels[per_row.argmax()])
         per_row, _ = row_errors(got[b], out["two_pass"][0][b])
         assert per_row.max() < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_polynomial_rows_in_chunks_of_bounded_coefficient_volume(emu_library, prec):
+    """The polynomial rows go through in chunks (coefficient planes of a chunk computed, then consumed): any chunk size gives
+    the bits of the single-chunk run."""
+    N = 1 << 17
+    x = np.random.default_rng(21).standard_normal(N - 77)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 96)
+    base, split, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_chunk_mb": 0})
+    assert split["poly"] >= 30
+    for mb in (1, 2, 48):
+        W, s2, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_chunk_mb": mb})
+        assert s2 == split
+        np.testing.assert_array_equal(W, base)
+    per_row, _ = row_errors(base, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
+    assert per_row.max() < TOL[prec]
