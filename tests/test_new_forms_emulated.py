@@ -228,15 +228,13 @@ def test_batch_rows_clipped_at_nyquist_on_the_band_passed_signals(emu_library, k
 def test_polynomial_rows_in_chunks_of_bounded_coefficient_volume(emu_library, prec):
     """The polynomial rows go through in chunks (coefficient planes of a chunk computed, then consumed): any chunk size gives
     the bits of the single-chunk run."""
-    N = 1 << 17
+    N = 1 << 16
     x = np.random.default_rng(21).standard_normal(N - 77)
     m = orc.Mother(orc.MORLET, 6)
-    sj = grid(N, 1.0, m, 96)
+    sj = grid(N, 1.0, m, 64)[24:]                        # (the band-limited end of the grid: parity of the form is test_polynomial_rows)
     base, split, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_chunk_mb": 0})
-    assert split["poly"] >= 30
-    for mb in (1, 2, 48):
+    assert split["poly"] >= 20
+    for mb in (1, 48):                                   # (1 MiB: two to three chunks at this size)
         W, s2, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_chunk_mb": mb})
         assert s2 == split
         np.testing.assert_array_equal(W, base)
-    per_row, _ = row_errors(base, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
-    assert per_row.max() < TOL[prec]
