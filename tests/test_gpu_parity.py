@@ -969,3 +969,44 @@ def test_stream_placement_of_the_signal_path_keeps_every_bit(hip_library):
             assert per_row.max() < 1e-8
         else:
             assert np.array_equal(W, base), opts
+
+
+def test_polynomial_rows_in_chunks_at_full_size(hip_library):
+    """fp64 Paul at the bench target: 150 MB of coefficient planes, so the polynomial rows go through in two chunks (planes
+    computed, consumed, next chunk).  Same bits as all rows at once; a few rows against the forms the polynomial one replaced
+    (the reference has no values for these scales: they are the rows its Paul filter turns into NaN, wavelet.py:111-115)."""
+    N = 1 << 20
+    m = orc.Mother(orc.PAUL, 4)
+    s0 = 2 / m.flambda()
+    sj_all = s0 * 2 ** (np.arange(256) * np.log2(N / s0) / 255)
+    x = np.random.default_rng(1234).standard_normal(N)
+    out = {}
+    for mb in (96, 0, 24):
+        plan = _hip.Plan(N, 64, max_rows=256, options={"tolerance": 1e-9, "poly_chunk_mb": mb})
+        labels = plan.classify(orc.PAUL, 4.0, 1.0, sj_all, N)
+        idx = [j for j, l in enumerate(labels) if l.startswith("poly/")]
+        assert len(idx) >= 120
+        sj = sj_all[idx]
+        xd, xh, Wd = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 16), _hip.DeviceBuffer(len(sj) * N * 16)
+        xd.upload(plan, x)
+        plan.transform(xd.ptr, N, orc.PAUL, 4.0, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+        assert plan.last_split()["poly"] == len(sj)
+        heavy = [k for k, j in enumerate(idx) if "K16384" in labels[j] or "K8192" in labels[j]]
+        out[mb] = np.concatenate([_download_rows(plan, Wd, k, 1, N, np.complex128) for k in heavy[::3]])
+        if mb == 96:
+            pick = heavy[::3][:4]
+            old = _hip.Plan(N, 64, max_rows=8, options={"tolerance": 1e-9, "poly": 0})
+            Wo = _hip.DeviceBuffer(len(pick) * N * 16)
+            old.transform(xd.ptr, N, orc.PAUL, 4.0, 1.0, sj[pick], xh.ptr, Wo.ptr, N, N)
+            assert old.last_split()["poly"] == 0
+            ref = Wo.download(old, (len(pick), N), np.complex128)
+            Wo.free()
+            old.close()
+            for i, k in enumerate(pick):
+                got = _download_rows(plan, Wd, k, 1, N, np.complex128)[0]
+                assert np.isfinite(got.view(np.float64)).all()
+                assert np.abs(got - ref[i]).max() < 1e-8 * np.abs(ref[i]).max()
+        for b in (xd, xh, Wd):
+            b.free()
+        plan.close()
+    assert np.array_equal(out[96], out[0]) and np.array_equal(out[24], out[0])
