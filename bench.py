@@ -654,6 +654,73 @@ def live_traffic(config, logn, rows, n_poly, csize):
 PRIME_MS = 80.0     # untimed device work before the W warm-up steps, see prime()
 
 
+def compact_line(out, detail_path):
+    """The driver's contract line: the contract fields, `roofline` and `cpu_baseline` as scalars, one `parity` summary and
+    ONE number per extra workload -- no per-class tables, no prose.  Everything else is in `detail_path`."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if d and k in d}
+
+    def r6(v):
+        return float(f"{v:.6g}") if isinstance(v, float) else v
+    line = pick(out, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data"])
+    line["config"] = pick(out["config"], ["workload", "N", "rows_total", "rows_per_gpu", "mother", "param", "tolerance",
+                                          "parallelism", "plan_options", "shard_diagnostic", "signals_in_flight"])
+    if not line["config"].get("plan_options"):
+        line["config"].pop("plan_options", None)
+    roof = out.get("roofline") or {}
+    line["roofline"] = pick(roof, ["bound", "kernel", "achieved", "peak", "unit", "frac", "whole_path_frac", "traffic",
+                                   "avg_launch_ms", "launches_per_step", "algorithmic_bytes_per_launch", "row_split"])
+    if roof.get("traffic_source"):
+        line["roofline"]["traffic_source"] = "live rocprofv3 PMC passes" if roof["traffic_source"].startswith("measured") else "committed PMC passes"
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = pick(cb, ["value", "unit", "cores", "kind", "reference_mounted"])
+        line["cpu_baseline"]["sample"] = cb.get("sample", "")[:96]
+        if "reference_as_is" in cb:
+            line["cpu_baseline"]["whole_function_value"] = cb["reference_as_is"]["value"]
+    if "parity" in out:
+        line["parity"] = pick(out["parity"], ["rows_checked", "rows_total", "max_row_err", "worst_row", "tolerance", "ok"])
+    if "from_idle" in out:
+        line["from_idle"] = pick(out["from_idle"], ["ms_per_step"])
+    for k in ("effective_warmup_steps", "cold_grid_ms"):
+        if k in out:
+            line[k] = out[k]
+    if "icwt" in out:
+        line["icwt_ms"] = out["icwt"]["ms"]
+    if "weak_scaling" in out:
+        line["weak_scaling"] = out["weak_scaling"]
+    ex = out.get("extra") or {}
+    short = {}
+    if "c2_roundoff" in ex:
+        short["c2_roundoff_ms"] = ex["c2_roundoff"]["ms_per_step"]
+    for c in ("c3_paul", "c3_dog", "paul64", "dog64"):
+        if c in ex and "value" in ex[c]:
+            short[c + "_gs"] = ex[c]["value"]
+            short[c + "_ms"] = ex[c]["ms_per_step"]
+            if ex[c].get("parity"):
+                short[c + "_max_row_err"] = ex[c]["parity"]["max_row_err"]
+    if "ms_per_step" in ex.get("c4_batch", {}):
+        short["c4_ms"] = ex["c4_batch"]["ms_per_step"]
+        short["c4_gs"] = ex["c4_batch"]["value"]
+    if "ms_per_call_median" in ex.get("c1_nino3_latency", {}):
+        short["c1_ms_per_call"] = ex["c1_nino3_latency"]["ms_per_call_median"]
+    for k in ("xwt_ms", "wct_ms", "mc_draw_ms", "wct_device_ms"):
+        if k in ex.get("c5_xwt_wct", {}):
+            short["c5_" + k] = ex["c5_xwt_wct"][k]
+    if short:
+        line["extra"] = short
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return r6(o)
+    return rnd(line)
+
+
 def measure(rt, config, args, rows_total, opts, want_cpu):
     wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
     if args.prime and not args.emulate:
@@ -730,6 +797,8 @@ def main():
                          "`from_idle` reports otherwise)")
     ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
                     help="do not measure the HBM traffic with rocprofv3 PMC passes inside this run (two short child runs)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file that receives the full result dictionary (stdout carries only the compact contract line)")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()
@@ -826,7 +895,18 @@ def main():
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # details (per-class tables, every kernel, the extra workloads in full) go to a FILE and to stderr; stdout's one and
+        # LAST line is the compact contract line (< 4 KB) the driver parses
+        detail = json.dumps(out)
+        for path in (args.detail, os.path.join(ROOT, "gpurun_out", "bench_detail.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None):
+            if path:
+                try:
+                    with open(path, "w") as f:
+                        f.write(detail + "\n")
+                except OSError:
+                    pass
+        print(detail, file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(out, args.detail)), flush=True)
 
 
 if __name__ == "__main__":
