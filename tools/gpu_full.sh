@@ -6,8 +6,8 @@ OUT=gpurun_out/$tag
 mkdir -p $OUT
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
-timeout 600 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; echo "bench rc=$?"
-for c in c3_paul c3_dog; do timeout 300 python bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
+timeout 600 python bench.py --detail $OUT/bench_c2.json > $OUT/bench_c2_line.json 2> $OUT/bench_c2.err; echo "bench rc=$?"
+for c in c3_paul c3_dog; do timeout 300 python bench.py --config $c --no-cpu-baseline --detail $OUT/bench_$c.json > $OUT/bench_${c}_line.json 2> $OUT/bench_$c.err; done
 python - $OUT <<'PY'
 import json,sys,glob
 for f in sorted(glob.glob(sys.argv[1]+"/bench_*.json")):

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 OUT=gpurun_out/$tag
 mkdir -p $OUT
-timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --detail $OUT/bench.json "$@" > $OUT/bench_line.json 2> $OUT/bench.err
 python - "$OUT/bench.json" <<'PY'
 import json,sys
 try:
