@@ -96,7 +96,7 @@ class Runtime:
         else:
             from pycwt_amd import _build
             _build.ensure(self.local)     # prebuilt library travels with the tree; compile once if it did not
-            self.lib = _hip.load()
+            self.lib = _hip.Library(os.path.abspath(args.lib)) if args.lib else _hip.load()
             torch.cuda.set_device(self.local)
             self.dev = torch.device("cuda", self.local)
             self.device_index = self.local
@@ -799,6 +799,7 @@ def main():
                     help="do not measure the HBM traffic with rocprofv3 PMC passes inside this run (two short child runs)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="file that receives the full result dictionary (stdout carries only the compact contract line)")
+    ap.add_argument("--lib", default=None, help="tuning: another build of libcwt_hip.so (a -D variant under tools/lab/)")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU rehearsal of the launch/stdout contract on the emulated kernel library (tests/emu); not a measurement")
     args = ap.parse_args()

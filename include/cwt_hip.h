@@ -137,14 +137,22 @@ int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
  * (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces the default of new plans. */
 int cwt_plan_set_tolerance(cwt_plan* plan, double rel_tol);
 /* target > 0: cwt_execute_host (the host-buffer call, which synchronises anyway) sets the plan's tolerance per call to
- * target * min(1, 6 / D), D = max|xhat| / (rms of the quietest octave of the spectrum) of that call, rounded down to a
- * power of ten and never below round-off -- the accuracy target then holds relative to every row's own peak for spectra of
- * any dynamic range (lines, red noise).  0 = off (the plan's own tolerance is used).  The device-resident entry points
- * never synchronise and never do this. */
+ * cwt_plan_auto_tolerance(target) of that call's spectrum.  0 = off (the plan's own tolerance is used).  The
+ * device-resident entry points never synchronise and never do this. */
 int cwt_plan_set_auto_tolerance(cwt_plan* plan, double target);
-/* Of a device-resident spectrum of n bins (one small kernel + a synchronising copy): max|xhat[k]|, rms|xhat[k]| and the rms
- * of the quietest octave [2^b, 2^(b+1)) of the positive half that has at least 64 bins (the rms itself for n < 256). */
+/* Of a device-resident spectrum of n bins (two small kernels + a synchronising copy): max|xhat[k]|, rms|xhat[k]| and the
+ * rms of the quietest stretch of the positive half at the resolution of a row's pass band: quarter-octave windows
+ * [2^b (4+q)/4, 2^b (5+q)/4) (single bins below bin 4), each pooled with its two neighbours (3/4 octave).  Every bin of
+ * 1 .. n/2 - 1 is in a window: a high-passed signal's quiet low end and any notch of 3/4 octave or more are seen (round 4
+ * looked at whole octaves from bin 64 up and missed both). */
 int cwt_spectrum_range(cwt_plan* plan, const void* xhat_dev, int64_t n, double* max_abs, double* rms_abs, double* floor_abs);
+/* The filter-relative tolerance that holds `target` relative to every row's own peak for THIS spectrum (nfft bins of the
+ * plan): target * min(1, 8 / D), D = max|xhat| / floor_abs of cwt_spectrum_range, rounded down to a power of sqrt(10), never
+ * below round-off (which is also the answer for a spectrum with an empty stretch or a non-finite bin).  The bound it rests
+ * on -- row error <= tolerance * D / 4 -- is measured, not proved (tests/test_tolerance_emulated.py: white and red noise,
+ * lines, high-passed and notched spectra); a signal whose energy in some row's band is far below the windows' floor (one
+ * isolated quiet bin among loud ones) can still exceed the target on that row.  Synchronises the plan's stream. */
+int cwt_plan_auto_tolerance(cwt_plan* plan, const void* xhat_dev, double target, double* rel_tol);
 int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 /* Block the host until everything queued by this plan has finished. */
 int cwt_plan_sync(cwt_plan* plan);

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("cwt_plan_get_tolerance", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("cwt_plan_set_auto_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_spectrum_range", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("cwt_plan_auto_tolerance", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
 ]
 
 
@@ -147,7 +148,9 @@ class PinnedPool:
         self.lib = lib
         self.free = {}
         self.total = 0
-        self.lock = threading.Lock()
+        # re-entrant: _release runs from __del__, and a garbage collection that starts while this thread holds the lock
+        # (any allocation inside it can trigger one) may finalise another pinned array on the same thread
+        self.lock = threading.RLock()
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -156,7 +159,7 @@ class PinnedPool:
             return None
         size = (nbytes + self.GRAIN - 1) & ~(self.GRAIN - 1)
         with self.lock:
-            stack = self.free.get(size)
+            stack = self.free.setdefault(size, [])            # (the free list exists before any release needs it)
             ptr = stack.pop() if stack else None
             if ptr is None:
                 if self.total + size > self.LIMIT:
@@ -278,10 +281,18 @@ class Plan:
 
     @_locked
     def spectrum_range(self, xhat_dev: int, n: int):
-        """(max|xhat|, rms|xhat|, rms of the quietest octave) of a device-resident spectrum."""
+        """(max|xhat|, rms|xhat|, rms of the quietest 3/4-octave stretch) of a device-resident spectrum."""
         mx, rms, fl = C.c_double(0), C.c_double(0), C.c_double(0)
         self.lib.check(self.lib.cwt_spectrum_range(self.h, _P(xhat_dev), n, C.byref(mx), C.byref(rms), C.byref(fl)))
         return mx.value, rms.value, fl.value
+
+    @_locked
+    def auto_tolerance(self, xhat_dev: int, target: float) -> float:
+        """The filter-relative tolerance that holds `target` for the device-resident spectrum of THIS call
+        (cwt_plan_auto_tolerance: one formula for the C host path and the Python shim)."""
+        v = C.c_double(0)
+        self.lib.check(self.lib.cwt_plan_auto_tolerance(self.h, _P(xhat_dev), float(target), C.byref(v)))
+        return v.value
 
     @_locked
     def tolerance(self) -> float:

@@ -30,6 +30,9 @@ using namespace cwt;
 namespace {
 
 thread_local std::string g_err;
+// bumped whenever a plan scratch buffer is freed and reallocated (grow, ensure_z): part of the key of a captured HIP graph,
+// whose kernels have those pointers baked in (option "graph")
+uint64_t g_scratch_gen = 0;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -1246,6 +1249,7 @@ int check_geometry(const cwt_plan* p) {
 int ensure_z(cwt_plan* p, int rows) {
   const size_t need = size_t(rows) * size_t(p->N) * 2 * p->esize();
   if (p->z_bytes >= need) return CWT_OK;
+  ++g_scratch_gen;
   if (p->Z) { HIPCHECK(hipStreamSynchronize(p->stream)); HIPCHECK(hipFree(p->Z)); p->Z = nullptr; p->z_bytes = 0; }
   if (hipMalloc(&p->Z, need) != hipSuccess) return fail(CWT_ENOMEM, "cannot allocate two-pass workspace");
   p->z_bytes = need;
@@ -1939,6 +1943,7 @@ hipError_t create_side_stream(hipStream_t* s) { return hipStreamCreateWithFlags(
 
 int grow(void** buf, size_t* have, size_t need, hipStream_t s) {
   if (*have >= need) return CWT_OK;
+  ++g_scratch_gen;
   if (*buf) { HIPCHECK(hipStreamSynchronize(s)); HIPCHECK(hipFree(*buf)); *buf = nullptr; *have = 0; }
   if (hipMalloc(buf, need) != hipSuccess) return fail(CWT_ENOMEM, "device allocation failed");
   *have = need;
@@ -2150,22 +2155,58 @@ int cwt_spectrum_range(cwt_plan* p, const void* xhat_dev, int64_t n, double* max
   else
     hipLaunchKernelGGL((k_spectrum_range<float>), dim3(groups), dim3(256), (256 + kOut + 2) * sizeof(double), p->stream,
                        static_cast<const float2*>(xhat_dev), long(n), part);
-  hipLaunchKernelGGL(k_spectrum_fold, dim3(1), dim3(64), 0, p->stream, part, groups, p->range_dev);
+  hipLaunchKernelGGL(k_spectrum_fold, dim3(1), dim3(192), 0, p->stream, part, groups, p->range_dev);
   HIPCHECK(hipGetLastError());
   double h[kOut] = {0};
   HIPCHECK(hipMemcpyAsync(h, p->range_dev, sizeof(h), hipMemcpyDeviceToHost, p->stream));
   HIPCHECK(hipStreamSynchronize(p->stream));
   *max_abs = std::sqrt(h[0]);
   *rms_abs = std::sqrt(h[1] / double(n));
-  // the quietest octave of the positive half with at least 64 bins (shorter ones fluctuate too much); short spectra: the rms
+  // The quietest stretch of the positive half at the resolution of a row's pass band: quarter-octave windows (single bins
+  // below bin 4), each pooled with its two neighbours (3/4 octave ~ the 1-sigma band of the narrowest built-in filter).
+  // Every bin from 1 to n/2 - 1 belongs to a window, so neither a quiet low end (a high-passed signal) nor a notch of
+  // 3/4 octave or more escapes; a narrower notch does not take a row's energy away.
+  std::vector<double> e, cnt;
+  for (int w = 0; w < SPECTRUM_WINDOWS; ++w) {
+    const int64_t lo = spectrum_window_lo(w), hi = std::min<int64_t>(spectrum_window_lo(w + 1), n / 2);
+    if (hi <= lo) continue;
+    e.push_back(h[2 + w]);
+    cnt.push_back(double(hi - lo));
+  }
   double fl = -1;
-  for (int b = 6; b < SPECTRUM_OCTAVES; ++b) {
-    const int64_t lo = int64_t(1) << b, hi = std::min<int64_t>(lo * 2, n / 2);
-    if (hi - lo < 64) continue;
-    const double r = std::sqrt(h[2 + b] / double(hi - lo));
+  for (size_t i = 0; i < e.size(); ++i) {
+    double es = e[i], cs = cnt[i];
+    if (i > 0) { es += e[i - 1]; cs += cnt[i - 1]; }
+    if (i + 1 < e.size()) { es += e[i + 1]; cs += cnt[i + 1]; }
+    const double r = std::sqrt(es / cs);
     if (fl < 0 || r < fl || r != r) fl = r;
   }
   *floor_abs = fl >= 0 ? fl : *rms_abs;
+  return CWT_OK;
+}
+
+// The filter-relative tolerance that keeps `target` relative to every row's own peak for a spectrum of dynamic range
+// D = max|xhat| / floor (cwt_spectrum_range): the truncation error of a row can reach tolerance * D / 4 (cwt_hip.h); white
+// noise has D ~ 5 ... 7, up to ~20 when one of the few-bin windows at the low end happens to be quiet (which then costs half
+// a decade of tolerance, not accuracy); a power of sqrt(10) (calls with like spectra share one cached row table), never
+// looser than the target, never below round-off.  A spectrum with an empty stretch or a non-finite bin: round-off.
+static double auto_tolerance_of(const cwt_plan* p, double target, double mx, double fl) {
+  const double round_off = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
+  double tol = target;
+  if (!(fl > 0) || !std::isfinite(mx)) return round_off;
+  const double excess = (mx / fl) / 8.0;
+  if (excess > 1.0) tol = std::pow(10.0, 0.5 * std::floor(2.0 * std::log10(target / excess)));
+  return std::max(tol, round_off);
+}
+
+int cwt_plan_auto_tolerance(cwt_plan* p, const void* xhat_dev, double target, double* rel_tol) {
+  if (!p || !xhat_dev || !rel_tol) return fail(CWT_EINVAL, "NULL argument");
+  if (!(target > 0) || target > 1e-2) return fail(CWT_EINVAL, "target must be in (0, 1e-2]");
+  double mx = 0, rms = 0, fl = 0;
+  const int rc = cwt_spectrum_range(p, xhat_dev, p->N, &mx, &rms, &fl);
+  if (rc) return rc;
+  p->last_range = fl > 0 ? mx / fl : std::numeric_limits<double>::infinity();
+  *rel_tol = auto_tolerance_of(p, target, mx, fl);
   return CWT_OK;
 }
 
@@ -2409,7 +2450,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   const std::vector<uint64_t> gkey = {uint64_t(reinterpret_cast<uintptr_t>(x_dev)), uint64_t(n0),
                                       uint64_t(reinterpret_cast<uintptr_t>(xhat_dev)), uint64_t(reinterpret_cast<uintptr_t>(W_dev)),
                                       uint64_t(ldw), uint64_t(ncols), uint64_t(reinterpret_cast<uintptr_t>(p->rt)), p->rt->build_id,
-                                      uint64_t(reinterpret_cast<uintptr_t>(p->stream))};
+                                      uint64_t(reinterpret_cast<uintptr_t>(p->stream)), g_scratch_gen};
   cwt_plan::GraphSlot* slot = nullptr;
   for (auto& g : p->graphs) if (g.key == gkey) slot = &g;
   if (slot && slot->exec) {
@@ -3010,19 +3051,9 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
     // accuracy target of THIS call = auto_target / (dynamic range of its spectrum relative to white noise), a power of
     // ten (so that calls with like spectra share one cached row table), never looser than the target itself
     rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
-    double mx = 0, rms = 0, fl = 0;
-    if (!rc) rc = cwt_spectrum_range(p, p->hxhat, p->N, &mx, &rms, &fl);
+    double tol = 0;
+    if (!rc) rc = cwt_plan_auto_tolerance(p, p->hxhat, p->auto_target, &tol);
     if (rc) return rc;
-    double tol = p->auto_target;
-    if (fl > 0 && std::isfinite(mx)) {
-      p->last_range = mx / fl;
-      const double excess = p->last_range / 6.0;           // white noise: max / quietest octave ~ 4 ... 5
-      if (excess > 1.0) tol = std::pow(10.0, std::floor(std::log10(p->auto_target / excess)));
-    } else if (!(fl > 0)) {
-      tol = 0.0;                                            // an empty octave (or a non-finite spectrum): round-off
-    }
-    const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
-    tol = std::max(tol, floor_tol);
     if (tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = tol; }
   }
   if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);

@@ -1699,13 +1699,29 @@ __global__ void k_coherence_hist(const T* __restrict__ R2, long ld, const long* 
     if (h[b]) atomicAdd(&hist[long(row) * nbins + b], (unsigned long long)h[b]);
 }
 
-// k_spectrum_range: out[0] = max_k |xhat[k]|^2, out[1] = sum_k |xhat[k]|^2 over the n bins, out[2 + b] = the sum over the
-// octave b of the positive half, 2^b <= k < min(2^(b+1), n/2): the dynamic range of the spectrum, by which a caller divides
-// the accuracy it wants (cwt_spectrum_range).  Two launches: every workgroup reduces a contiguous slice (fp64 accumulation; a
-// slice touches few octaves, found by the leading-zero count of the bin) into part[workgroup][2 + OCTAVES]; one workgroup
-// folds those.  (One workgroup for the whole spectrum, as at first, read 134 MB in 2.5 ms at N = 2^23.)
+// k_spectrum_range: out[0] = max_k |xhat[k]|^2, out[1] = sum_k |xhat[k]|^2 over the n bins, out[2 + w] = the sum over the
+// QUARTER-OCTAVE window w = 4 b + q of the positive half, 2^b (4 + q) / 4 <= k < 2^b (5 + q) / 4 (bounds rounded up; below
+// bin 4 most windows are empty and the others hold one bin): the dynamic range of the spectrum at the resolution of a
+// row's pass band (the narrowest built-in filter, Morlet(6), is ~3/4 octave wide at its 1-sigma points), by which a caller
+// divides the accuracy it wants (cwt_spectrum_range).  Two launches: every workgroup reduces a contiguous slice (fp64
+// accumulation; the windows a slice touches follow from the leading-zero counts of its ends) into
+// part[workgroup][2 + WINDOWS]; one workgroup folds those.
 constexpr int SPECTRUM_OCTAVES = 32;
-constexpr int SPECTRUM_SLOTS = 2 + SPECTRUM_OCTAVES;
+constexpr int SPECTRUM_WINDOWS = 4 * SPECTRUM_OCTAVES;
+constexpr int SPECTRUM_SLOTS = 2 + SPECTRUM_WINDOWS;
+// first bin of window w (w = SPECTRUM_WINDOWS: one past the last)
+__host__ __device__ inline long spectrum_window_lo(int w) {
+  const int b = w >> 2, q = w & 3;
+  const long num = (1L << b) * (4 + q);
+  return (num + 3) >> 2;
+}
+__host__ __device__ inline int spectrum_window_of(long k) {   // k >= 1
+  int b = 0;
+  while ((2L << b) <= k) ++b;
+  int w = 4 * b;
+  while (w + 1 < 4 * b + 4 && spectrum_window_lo(w + 1) <= k) ++w;
+  return w;
+}
 template <typename T>
 __global__ void __launch_bounds__(256) k_spectrum_range(const cplx<T>* __restrict__ xhat, long n, double* __restrict__ part) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
@@ -1714,16 +1730,17 @@ __global__ void __launch_bounds__(256) k_spectrum_range(const cplx<T>* __restric
   if (threadIdx.x < SPECTRUM_SLOTS) acc[threadIdx.x] = 0;
   const long per = (n + gridDim.x - 1) / gridDim.x;
   const long k0 = long(blockIdx.x) * per, k1 = k0 + per < n ? k0 + per : n;
-  // octaves this slice can touch: [b_lo, b_hi]
-  const int b_lo = k0 < 1 ? 0 : 63 - __builtin_clzll((unsigned long long)k0);
-  const int b_hi = k1 < 2 ? 0 : 63 - __builtin_clzll((unsigned long long)(k1 - 1));
+  // windows this slice can touch: [w_lo, w_hi]
+  const int w_lo = k0 < 1 ? 0 : spectrum_window_of(k0);
+  const int w_hi = k1 < 2 ? 0 : spectrum_window_of(k1 - 1);
   double mx = 0, sm = 0;
   __syncthreads();
-  for (int b = b_lo; b <= b_hi && b < SPECTRUM_OCTAVES; ++b) {
-    long lo = 1L << b, hi = 2L << b;
+  for (int w = w_lo; w <= w_hi && w < SPECTRUM_WINDOWS; ++w) {
+    long lo = spectrum_window_lo(w), hi = spectrum_window_lo(w + 1);
     if (hi > n / 2) hi = n / 2;
     if (lo < k0) lo = k0;
     if (hi > k1) hi = k1;
+    if (hi <= lo) continue;                                   // (uniform: an empty window below bin 4, or outside the slice)
     double o = 0;
     for (long k = lo + threadIdx.x; k < hi; k += 256) {
       const cplx<T> v = xhat[k];
@@ -1735,7 +1752,7 @@ __global__ void __launch_bounds__(256) k_spectrum_range(const cplx<T>* __restric
       if (int(threadIdx.x) < s2) red[threadIdx.x] += red[threadIdx.x + s2];
       __syncthreads();
     }
-    if (threadIdx.x == 0) acc[2 + b] = red[0];
+    if (threadIdx.x == 0) acc[2 + w] = red[0];
     __syncthreads();
   }
   for (long k = k0 + threadIdx.x; k < k1; k += 256) {          // (a second pass over the slice: it sits in the L2 now)
@@ -1764,7 +1781,7 @@ __global__ void __launch_bounds__(256) k_spectrum_range(const cplx<T>* __restric
 }
 
 // out[q] = fold of part[g][q] over the g workgroups of k_spectrum_range (max for q = 0, sums otherwise); one workgroup.
-__global__ void __launch_bounds__(64) k_spectrum_fold(const double* __restrict__ part, int groups, double* __restrict__ out) {
+__global__ void __launch_bounds__(192) k_spectrum_fold(const double* __restrict__ part, int groups, double* __restrict__ out) {
   const int q = threadIdx.x;
   if (q >= SPECTRUM_SLOTS) return;
   double r = 0;

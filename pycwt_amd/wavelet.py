@@ -56,9 +56,11 @@ def _apply_tolerance(plan):
 def set_tolerance(rel_tol="auto"):
     """Accuracy target of every transform of this module from now on.
 
-    "auto" (default): max|W - W_reference| / max|W_reference| <= 1e-9 per row (3e-5 in complex64) for ANY signal: the
-    engine's truncations are relative to the filter, so each call divides the target by the measured dynamic range of its
-    spectrum (`cwt_plan_set_auto_tolerance` / `cwt_spectrum_range`).  A float: the engine's filter-relative tolerance
+    "auto" (default): aims at max|W - W_reference| / max|W_reference| <= 1e-9 per row (3e-5 in complex64) whatever the
+    spectrum's shape: the engine's truncations are relative to the filter, so each call divides the target by the measured
+    dynamic range of its spectrum -- largest bin over the quietest 3/4-octave stretch, `cwt_plan_auto_tolerance`.  Measured
+    on white / red noise, lines, high-passed and notched signals (tests/test_tolerance_emulated.py), not a proof: a signal
+    with almost no energy inside one row's band but a lot just outside can exceed the target on that row.  A float: the engine's filter-relative tolerance
     itself, for every call (`cwt_plan_set_tolerance`; 1e-16 = every truncation below fp64 rounding).  None / 0: the
     engine's default, round-off."""
     global _tolerance
@@ -124,13 +126,7 @@ def _transform(plan, x_host, xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr, aut
         target = _auto(plan) if plan.nfft > 4096 and auto else 0.0
         if target:      # automatic accuracy: the tolerance of this call from the dynamic range of its spectrum
             plan.forward_fft(xd_ptr, n0, xh_ptr)
-            mx, _, floor = plan.spectrum_range(xh_ptr, plan.nfft)
-            tol = target
-            if not floor > 0:
-                tol = 0.0
-            elif np.isfinite(mx) and mx / floor > 6.0:
-                tol = 10.0 ** np.floor(np.log10(target * 6.0 * floor / mx))
-            plan.set_tolerance(max(tol, 1e-16 if plan.precision == 64 else 1e-8))
+            plan.set_tolerance(plan.auto_tolerance(xh_ptr, target))
         plan.transform(xd_ptr, n0, kind, param, dt, sj, xh_ptr, W_ptr, n0, n0)
     else:
         plan.forward_fft(xd_ptr, n0, xh_ptr)
@@ -205,6 +201,7 @@ def _nan_rows(mother, sj, N, dt):
 
 
 _geometry_cache = {}
+_geometry_lock = threading.Lock()
 
 
 def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
@@ -216,7 +213,8 @@ def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
     if freqs is None and hasattr(mother, "device_id"):
         try:
             key = (type(mother), mother.device_id(), n0, dt, dj, s0, J, pad)
-            hit = _geometry_cache.get(key)
+            with _geometry_lock:
+                hit = _geometry_cache.get(key)
             if hit is not None:
                 return hit[0]
         except TypeError:                                   # an unhashable argument (array-valued dt ...): no cache
@@ -230,10 +228,11 @@ def _geometry(mother, n0, dt, dj, s0, J, freqs, pad):
     geo = (N, sj, freqs, _coi(mother, n0, dt), ftfreqs[1:N // 2] / (2 * np.pi), bad)
     if key is not None:
         nbytes = sum(a.nbytes for a in geo[1:] if isinstance(a, np.ndarray))
-        held = sum(v[1] for v in _geometry_cache.values())
-        if len(_geometry_cache) >= 64 or held + nbytes > (128 << 20):      # (a 2^20-point call keeps 12 MB here)
-            _geometry_cache.clear()
-        _geometry_cache[key] = (geo, nbytes)
+        with _geometry_lock:
+            held = sum(v[1] for v in _geometry_cache.values())
+            if len(_geometry_cache) >= 64 or held + nbytes > (128 << 20):      # (a 2^20-point call keeps 12 MB here)
+                _geometry_cache.clear()
+            _geometry_cache[key] = (geo, nbytes)
     return geo
 
 
@@ -311,8 +310,17 @@ def cwt(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, pre
         # wavelet.py:91 transforms a complex signal as it is; the engine's forward transform is real-input, and the whole
         # path is linear: W(x) = W(Re x) + i W(Im x), likewise the spectrum of the 5th return value
         z = np.asarray(signal)
-        a = cwt(z.real, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
-        b = cwt(z.imag, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
+        zr, zi = z.real, z.imag
+        nonfinite = ~(np.isfinite(zr) & np.isfinite(zi))
+        if nonfinite.any():
+            # one NaN / inf sample makes every bin of the reference's spectrum NaN, whichever part it sits in: both parts
+            # must take the "whole matrix is NaN, every row kept" branch (wavelet.py:111-115), or they would drop
+            # different sets of rows
+            zr, zi = zr.copy(), zi.copy()
+            zr[nonfinite] = np.nan
+            zi[nonfinite] = np.nan
+        a = cwt(zr, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
+        b = cwt(zi, dt, dj, s0, J, mother, freqs, precision=precision, device=device, pad=pad)
         fft5 = a[4] + 1j * b[4]
         if z.dtype == np.complex64:
             fft5 = fft5.astype(np.complex64)            # scipy.fftpack keeps single precision (wavelet.py:91, :123-124)
@@ -683,10 +691,21 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
         with plan.lock:
             xd, xh = alloc(n0 * es), alloc(N * 2 * es)
             W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
+            target = _auto(plan) if plan.nfft > 4096 and auto else 0.0
+            if target and np.isfinite(x1).all() and np.isfinite(x2).all():
+                # automatic accuracy: ONE tolerance for the pair, the tighter of the two spectra's (a red series paired with
+                # a white one, `surrogates='ar1'` with unlike coefficients); it also stays for the later draws of a
+                # Monte-Carlo loop (auto=False there), whose series come from the same two processes
+                tols = []
+                for x in (x1, x2):
+                    xd.upload(plan, np.ascontiguousarray(x, dtype=plan.real))
+                    plan.forward_fft(xd.ptr, n0, xh.ptr)
+                    tols.append(plan.auto_tolerance(xh.ptr, target))
+                plan.set_tolerance(min(tols))
             for x, W in ((x1, W1), (x2, W2)):
                 xh_ = np.ascontiguousarray(x, dtype=plan.real)
                 xd.upload(plan, xh_)
-                _transform(plan, xh_, xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, auto)
+                _transform(plan, xh_, xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, auto=False)
             P, Cx, ang = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es), alloc(rows * n0 * es)
             plan.wct_products(W1.ptr, W2.ptr, sj, n0, n0, P.ptr, Cx.ptr, ang.ptr)
             spec = alloc(rows * N * 2 * es)

@@ -173,6 +173,24 @@ def test_edge_complex_signal(emulated, dtype):
     _same_tuple(o, r, rtol=1e-11 if dtype == np.complex128 else 1e-6)
 
 
+@pytest.mark.parametrize("part", ["real", "imag"])
+def test_edge_complex_signal_with_a_nan_in_one_part_keeps_every_row(emulated, part):
+    """Paul at a grid where some rows are 'bad' (wavelet.py:111-115) and a complex signal with a NaN in ONE part:
+    the reference's spectrum is NaN throughout, so every row is NaN and all rows are kept; the two real transforms of the
+    shim must not drop different row sets."""
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal(400) + 1j * rng.standard_normal(400)
+    z[37] = complex(np.nan, z[37].imag) if part == "real" else complex(z[37].real, np.nan)
+    args = (0.05, 0.5, 1.0, 18, "paul")
+    clean = _ref().cwt(np.nan_to_num(z), *args)
+    assert clean[0].shape[0] < 19                      # the grid does have rows the reference drops for a finite signal
+    o, r = _both(z, *args)
+    assert o[0].shape == r[0].shape == (19, 400)
+    assert np.isnan(r[0]).all() and np.isnan(o[0].real).all() and np.isnan(o[0].imag).all()
+    for a, b in zip(o[1:4], r[1:4]):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-12)
+
+
 def test_edge_every_paul_row_nan_keeps_all_rows_as_nan(emulated):
     """wavelet.py:111-115: when EVERY row is NaN the reference keeps all rows; W is NaN throughout."""
     x = np.random.default_rng(6).standard_normal(300)

@@ -102,7 +102,9 @@ def test_automatic_mode_keeps_the_target_on_white_noise(emu_library, monkeypatch
     x = np.random.default_rng(3).standard_normal(N)
     plan = _hip.Plan(N, 64, max_rows=8, lib=emu_library, options={"auto_tolerance": 1e-9})
     plan.execute_host(x, orc.MORLET, 6, 1.0, np.array([4.0, 40.0, 400.0]), want_xhat=False)
-    assert plan.tolerance() == pytest.approx(1e-9)
+    # (D = largest bin / quietest 3/4-octave stretch is 5 ... 7 for white noise, up to ~20 when one of the single-bin windows at
+    # the low end happens to be quiet: at most one decade below the target)
+    assert 1e-10 <= plan.tolerance() <= 1e-9 * (1 + 1e-12)
     plan.close()
 
 
@@ -138,11 +140,26 @@ def test_largest_scales_keep_their_few_bins(emu_library, monkeypatch, kind, para
     assert per_row.max() < tol + (1e-13 if prec == 64 else 2e-5), per_row
 
 
+def window_floor(a, n):
+    """NumPy restatement of cwt_spectrum_range's floor: quarter-octave windows [ceil(2^b (4+q)/4), ceil(2^b (5+q)/4)) of the
+    bins 1 .. n/2 - 1, each pooled with its two neighbours; min of the pooled rms."""
+    e, c = [], []
+    for w in range(128):
+        b, q = divmod(w, 4)
+        lo, hi = -(-(1 << b) * (4 + q) // 4), min(-(-(1 << b) * (5 + q) // 4), n // 2)
+        if hi > lo:
+            e.append(float((a[lo:hi] ** 2).sum()))
+            c.append(hi - lo)
+    if not e:
+        return None
+    return min(np.sqrt(sum(e[max(i - 1, 0):i + 2]) / sum(c[max(i - 1, 0):i + 2])) for i in range(len(e)))
+
+
 @pytest.mark.parametrize("prec", [64, 32])
 @pytest.mark.parametrize("n", [1, 16, 300, 4096, 5000, 65536, 100001])
 def test_spectrum_range_against_numpy(emu_library, prec, n):
     """cwt_spectrum_range (a two-stage reduction over slices of the spectrum): largest bin, rms, and the rms of the quietest
-    octave of the positive half with at least 64 bins."""
+    3/4-octave stretch (quarter-octave windows pooled with their neighbours) of the positive half."""
     cplx = np.complex128 if prec == 64 else np.complex64
     rng = np.random.default_rng(n)
     z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.exp(-np.arange(n) / max(n / 6, 1.0))     # a sloping spectrum
@@ -154,12 +171,44 @@ def test_spectrum_range_against_numpy(emu_library, prec, n):
     a = np.abs(z.astype(np.complex128))
     assert mx == pytest.approx(a.max(), rel=1e-12)
     assert rms == pytest.approx(np.sqrt((a ** 2).mean()), rel=1e-12)
-    octaves = [np.sqrt((a[lo:min(2 * lo, n // 2)] ** 2).mean()) for lo in (1 << b for b in range(6, 32))
-               if min(2 * lo, n // 2) - lo >= 64]
-    assert floor == pytest.approx(min(octaves) if octaves else np.sqrt((a ** 2).mean()), rel=1e-12)
+    want = window_floor(a, n)
+    assert floor == pytest.approx(want if want is not None else np.sqrt((a ** 2).mean()), rel=1e-12)
     z[n // 3] = np.nan                                       # a NaN bin poisons the maximum (and the sums)
     buf.upload(plan, z)
     mx, rms, floor = plan.spectrum_range(buf.ptr, n)
     assert np.isnan(mx) and np.isnan(rms)
     buf.free()
     plan.close()
+
+
+def shaped_noise(n, gain, seed=21):
+    """White noise whose spectrum is multiplied by gain(k) (k = bin of the one-sided spectrum)."""
+    X = np.fft.rfft(np.random.default_rng(seed).standard_normal(n))
+    return np.fft.irfft(X * gain(np.arange(X.size)), n)
+
+
+@pytest.mark.parametrize("gain,att,label", [
+    (lambda k: np.where(k < 64, 1e-7, 1.0), 1e-7, "high-passed: bins below 64 attenuated by 1e-7 (ADVICE r04)"),
+    (lambda k: np.where(k < 8, 1e-6, 1.0), 1e-6, "the lowest 8 bins attenuated by 1e-6"),
+    (lambda k: np.where((k >= 900) & (k < 1800), 1e-6, 1.0), 1e-6, "a one-octave notch"),
+    (lambda k: np.where(k > 4000, 1e-5, 1.0), 1e-5, "low-passed"),
+])
+def test_automatic_mode_on_high_passed_and_notched_spectra(emu_library, monkeypatch, gain, att, label):
+    """the round-4 floor looked at whole octaves from bin 64 up, so a quiet low end or a notch narrower
+    than an octave left the automatic mode at 1e-9, and a large-scale row centred in the quiet stretch came out at 7e-5 of its
+    own peak.  With quarter-octave windows down to bin 1 the tolerance follows (round-off here) and what is left is the
+    arithmetic's own rounding, ~ eps * (largest bin / the row's bins) -- the reference's pocketfft leaves as much: 9e-9 in the
+    first case, against 7.4e-5 before."""
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    x = shaped_noise(N, gain)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = grid(N, 1.0, m, 64)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)
+    plan = _hip.Plan(N, 64, max_rows=len(sj), lib=emu_library, options={"ols_min_logn": 15, "auto_tolerance": 1e-9})
+    W, _ = plan.execute_host(x, orc.MORLET, 6, 1.0, sj, want_xhat=False)
+    used = plan.tolerance()
+    plan.close()
+    per_row = row_errors(W, ref)[0]
+    print(f"{label}: tolerance {used:.0e}, worst row {per_row.argmax()} at {per_row.max():.1e}")
+    assert used <= 1e-13, (label, used)                 # five to seven orders of dynamic range were seen
+    assert per_row.max() < max(1e-9, 3e-15 / att), (label, used, per_row.argmax(), per_row.max())
