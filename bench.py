@@ -224,10 +224,12 @@ class Workload:
         t0 = time.perf_counter()
         self.run_steps(steps)
         self.join()          # (option "pipeline": W of every step complete on the plan's stream; a no-op otherwise)
+        self.host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3      # host time to QUEUE a step (diagnostic)
         rt.fence()
         elapsed = rt.max_over_ranks(time.perf_counter() - t0)
         ms = elapsed / steps * 1e3
-        return {"ms_per_step": ms, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9}
+        return {"ms_per_step": ms, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9,
+                "host_enqueue_ms_per_step": self.host_enqueue_ms}
 
     def prime(self, min_ms):
         """Untimed steps until at least `min_ms` of wall time have passed: brings the device from its idle clock to its
@@ -872,7 +874,7 @@ def main():
         weak = measure(rt, args.config, args, args.rows * world, opts, want_cpu=False)
         out["weak_scaling"] = {"value": weak["value"], "ms_per_step": weak["ms_per_step"], "rows_total": args.rows * world,
                                "rows_per_gpu": args.rows}
-    for k in ("effective_warmup_steps", "icwt"):
+    for k in ("effective_warmup_steps", "icwt", "host_enqueue_ms_per_step"):
         if k in head:
             out[k] = head[k]
     if single and args.config == "c2" and not args.no_extra and not opts and not args.emulate:

@@ -353,6 +353,7 @@ struct cwt_plan {
   int lane_turn = 0;
   int pipeline = 0;                   // option
   int pipe_prio = 1;                  // option: prep streams at high priority (they are short and everything waits for them)
+  int pipe_one_lane = 0;
   int pipe_map = 1;                   // option: 0 = preparation on streams of its own, 1 = one in-order chain per row form
   bool pipe_open = false;             // row streams hold work the plan's stream has not joined
   bool pipe_ready = false;            // streams / events below exist
@@ -2186,7 +2187,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
     p->tolerance = value ? std::pow(10.0, -double(value)) : 0.0;
   }
   else if (k == "pipeline") p->pipeline = value != 0;
-  else if (k == "pipe_map") p->pipe_map = value != 0;
+  else if (k == "pipe_map") p->pipe_map = int(value);
+  else if (k == "pipe_one_lane") p->pipe_one_lane = value != 0;
   else if (k == "pipe_prio") { if (p->pipe_ready) return fail(CWT_EINVAL, "pipe_prio must be set before the first pipelined call"); p->pipe_prio = value != 0; }
   else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
@@ -2555,18 +2557,20 @@ int transform_pipelined(cwt_plan* p, const void* x_dev, int64_t n0, const Mother
     if (rc) return rc;
   }
   cwt_plan::Lane& L = p->lane[p->lane_turn];
-  p->lane_turn ^= 1;
+  if (!p->pipe_one_lane) p->lane_turn ^= 1;        // (pipe_one_lane: timing experiment only -- calls then share their scratch)
   LaneGuard lane(p, L);
   cplx<T>* W = static_cast<cplx<T>*>(W_dev);
-  hipStream_t* pr = p->pr;
+  hipStream_t pr_all[3] = {p->pr[0], p->pr[1], p->pr[2]};
+  if (p->pipe_map == 2) pr_all[1] = pr_all[2] = p->pr[0];     // pipe_map 2: every row kernel on ONE stream (overlap-save, band-passed, polynomial), prep as in 0
+  hipStream_t* pr = pr_all;
   // pipe_map 0: the preparation on streams of its own (every prep kernel may run beside any row kernel);
   // pipe_map 1: three in-order chains, one per row form -- [block spectra, overlap-save rows], [forward FFT, band-passed
   //             signal, its rows], [bands, coefficients, polynomial rows] -- the preparation of a form follows the previous
   //             call's rows of the same form on the same stream (the stagger of the one-call schedule, no extra queues)
   hipStream_t pq_sep[3] = {p->pq[0], p->pq[1], p->pq[2]};
   hipStream_t pq_chain[3] = {pr[2], pr[1], pr[2]};
-  hipStream_t* pq = p->pipe_map ? pq_chain : pq_sep;
-  hipStream_t poly_prep = p->pipe_map ? pr[0] : pq[0];
+  hipStream_t* pq = p->pipe_map == 1 ? pq_chain : pq_sep;
+  hipStream_t poly_prep = p->pipe_map == 1 ? pr[0] : pq[0];
   const bool need_xhat = rt->n_poly || rt->n_aols || xhat_user;
   // buffers first (growing one synchronises the device; happens in the first calls only)
   if (rt->n_ols) rc = grow(&p->xs, &p->xs_bytes, size_t(rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
