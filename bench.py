@@ -212,18 +212,12 @@ class Workload:
                 pending = rt.dist.broadcast(self.xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
             self.compute(self.xbuf[i & 1], i)
 
-    def join(self):
-        for lane in self.lanes:
-            lane[0].join()
-
     def timed(self, steps, warmup):
         rt = self.rt
         self.run_steps(warmup)
-        self.join()
         rt.fence()
         t0 = time.perf_counter()
         self.run_steps(steps)
-        self.join()          # (option "pipeline": W of every step complete on the plan's stream; a no-op otherwise)
         self.host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3      # host time to QUEUE a step (diagnostic)
         rt.fence()
         elapsed = rt.max_over_ranks(time.perf_counter() - t0)
@@ -240,7 +234,6 @@ class Workload:
         t0 = time.perf_counter()
         while True:
             self.run_steps(8)
-            self.join()
             rt.fence()
             done += 8
             spent = rt.max_over_ranks(time.perf_counter() - t0) * 1e3

@@ -156,29 +156,6 @@ int cwt_plan_auto_tolerance(cwt_plan* plan, const void* xhat_dev, double target,
 int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 /* Block the host until everything queued by this plan has finished. */
 int cwt_plan_sync(cwt_plan* plan);
-/* ---- Pipelined mode: consecutive cwt_transform calls that overlap ---------------------------------------------------------
- * (What the reference does one call at a time, wavelet.py:91-106, for a caller that streams signals through the same scale
- * grid: the Monte-Carlo loop of wavelet.py:609-630, a batch, a rank of the sharded transform.)
- * Option "pipeline" = 1: a cwt_transform call whose rows are all of the forms P / O / A (cwt_plan_row_classes) splits into
- * its PREPARATION -- forward FFT, block spectra, bands and interval coefficients, band-passed signal: short latency-bound
- * launches that write plan scratch only -- and its ROWS, the kernels that write W.  Rows run in call order on the plan's row
- * streams; the preparation of call c+1 runs beside the rows of call c (every scratch buffer exists twice; call c+2's
- * preparation waits for call c's rows).  Contract in this mode:
- *   - the signal of a call must be ready on the plan's stream at call time, or on the stream given to
- *     cwt_plan_set_input_stream (e.g. the stream a collective or an upload delivers it on); it must stay untouched until the
- *     call's preparation has run (cwt_plan_join / cwt_plan_sync, or two more transforms);
- *   - W_dev and xhat_dev of the pipelined calls are complete ON THE PLAN'S STREAM only after cwt_plan_join(plan) (stream
- *     order, no host wait) or cwt_plan_sync(plan) (host wait).  Every other entry point of the plan joins first, so mixing
- *     calls is safe, merely not overlapped.  Consecutive pipelined calls may name the same W_dev: rows are written in call order;
- *   - calls that need a new row table (other scales, mother, tolerance), other row forms, batches, option "profile" or "graph"
- *     join and run the ordinary way.
- * "pipe_prio" = 1 (default; before the first pipelined call): the preparation streams get the device's highest priority. */
-int cwt_plan_join(cwt_plan* plan);
-/* enable != 0: the signal of the next pipelined calls becomes ready on `hip_stream` (NULL = the legacy default stream);
- * enable = 0: on the plan's own stream (default). */
-int cwt_plan_set_input_stream(cwt_plan* plan, void* hip_stream, int enable);
-/* Number of cwt_transform calls that took the pipelined path so far (diagnostic). */
-int cwt_plan_pipelined_calls(cwt_plan* plan, int64_t* calls);
 
 /* ---- device memory helpers (so a NumPy-only host needs no other runtime) */
 int cwt_malloc(int device, void** ptr_dev, size_t bytes);

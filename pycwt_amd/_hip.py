@@ -82,9 +82,6 @@ SYMBOLS = [
     ("cwt_plan_set_auto_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_spectrum_range", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("cwt_plan_auto_tolerance", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
-    ("cwt_plan_join", C.c_int, [_P]),
-    ("cwt_plan_set_input_stream", C.c_int, [_P, _P, C.c_int]),
-    ("cwt_plan_pipelined_calls", C.c_int, [_P, C.POINTER(C.c_int64)]),
 ]
 
 
@@ -296,22 +293,6 @@ class Plan:
         v = C.c_double(0)
         self.lib.check(self.lib.cwt_plan_auto_tolerance(self.h, _P(xhat_dev), float(target), C.byref(v)))
         return v.value
-
-    @_locked
-    def join(self):
-        """Pipelined mode (option "pipeline"): the plan's stream waits for every row queued so far (cwt_plan_join)."""
-        self.lib.check(self.lib.cwt_plan_join(self.h))
-
-    @_locked
-    def set_input_stream(self, stream_handle, enable=True):
-        """Pipelined mode: the signals of the next transforms become ready on this stream (cwt_plan_set_input_stream)."""
-        self.lib.check(self.lib.cwt_plan_set_input_stream(self.h, _P(stream_handle or 0), int(bool(enable))))
-
-    @_locked
-    def pipelined_calls(self) -> int:
-        n = C.c_int64(0)
-        self.lib.check(self.lib.cwt_plan_pipelined_calls(self.h, C.byref(n)))
-        return n.value
 
     @_locked
     def tolerance(self) -> float:

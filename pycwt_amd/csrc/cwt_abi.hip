@@ -46,16 +46,6 @@ int fail(int code, const std::string& msg) {
       return fail(CWT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
-// Entry points other than cwt_transform see the plan as if nothing were in flight: pipelined work is joined into the plan's
-// stream first (pipe_join, below).
-#define PIPE_SETTLE(p)                                     \
-  do {                                                     \
-    if ((p)->pipe_open) {                                  \
-      const int rc_settle_ = pipe_join(p);                 \
-      if (rc_settle_) return rc_settle_;                   \
-    }                                                      \
-  } while (0)
-
 enum KernelClass { KC_FWD_SMALL, KC_FWD_A, KC_FWD_B, KC_SMALL, KC_DIRECT, KC_NARROW, KC_NARROW_MANY, KC_NARROW_BIG,
                    KC_PASS_A, KC_PASS_B, KC_ICWT, KC_ELEMENTWISE, KC_OLS_FWD, KC_OLS, KC_OLS_SMALL, KC_AOLS_PRE, KC_AOLS,
                    KC_POLY_COEF, KC_POLY, KC_COUNT };
@@ -332,47 +322,9 @@ struct cwt_plan {
   hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
-  // ---- pipelined mode (option "pipeline", cwt_plan_set_input_stream, cwt_plan_join) ---------------------------------------
-  // Consecutive cwt_transform calls overlap: the PREPARATION of a call (forward FFT, block spectra, bands + interval
-  // coefficients, band-passed signal: ~25 short launches that write plan scratch only and depend on nothing but the signal)
-  // runs on the prep streams beside the ROWS of the previous call (the kernels that write W), which run in call order on the
-  // row streams.  Every scratch buffer exists twice (lane = call parity); a lane's preparation waits for the rows of the call
-  // two back.  The plan's stream sees W only after cwt_plan_join (any other entry point joins first).
-  struct Lane {
-    void* Z = nullptr; size_t z_bytes = 0;
-    void* xs = nullptr; size_t xs_bytes = 0;
-    void* pcoef = nullptr; size_t pcoef_bytes = 0;
-    void* pband = nullptr; size_t pband_bytes = 0;
-    void* xm = nullptr; size_t xm_bytes = 0;
-    void* xsa = nullptr; size_t xsa_bytes = 0;
-    void* hxhat = nullptr; size_t hxhat_bytes = 0;
-    hipEvent_t done[3] = {nullptr, nullptr, nullptr};   // rows of the last call on this lane, per row stream
-    bool used = false;
-  };
-  Lane lane[2];
-  int lane_turn = 0;
-  int pipeline = 0;                   // option
-  int pipe_prio = 1;                  // option: prep streams at high priority (they are short and everything waits for them)
-  int pipe_one_lane = 0;
-  int pipe_map = 1;                   // option: 0 = preparation on streams of its own, 1 = one in-order chain per row form
-  bool pipe_open = false;             // row streams hold work the plan's stream has not joined
-  bool pipe_ready = false;            // streams / events below exist
-  hipStream_t pq[3] = {nullptr, nullptr, nullptr};   // prep streams: [0] forward FFT + polynomial prep, [1] block spectra, [2] band-passed signal
-  hipStream_t pr[3] = {nullptr, nullptr, nullptr};   // row streams: [0] polynomial rows, [1] overlap-save rows, [2] rows on the band-passed signal + spectrum copy
-  hipEvent_t ev_in = nullptr, ev_pfork = nullptr, ev_xhat = nullptr, ev_xs = nullptr, ev_coef = nullptr, ev_xsa = nullptr;
-  void* in_stream = nullptr;          // cwt_plan_set_input_stream: where the signal of a pipelined call becomes ready
-  bool in_stream_set = false;
-  const void* pipe_rt = nullptr;      // row table (slot + build) of the pipelined calls in flight: another one joins first
-  uint64_t pipe_build = 0;
-  uint64_t pipe_calls = 0;            // transforms that went through the pipelined path (diagnostic)
-
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
 };
 
-namespace {
-int pipe_join(cwt_plan* p);
-void pipe_drain(cwt_plan* p);
-}
 namespace {
 
 // Default accuracy targets: every truncation of the fast forms below the arithmetic's own rounding.  The truncations are
@@ -1617,10 +1569,8 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
 
 // Rows clipped at Nyquist (k_aols_*): band-passed complex signal x_M = IFFT_N(xhat mask) through the two-pass kernels
 // (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
-// st_rows != nullptr (pipelined mode, one signal): the preparation on st, event `ready` recorded behind it, the rows on st_rows.
 template <typename T, int LOGP>
-int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
-                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
+int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
@@ -1655,27 +1605,20 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
       hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st, xm,
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
-    hipStream_t sr = st;
-    if (!rc && st_rows) {
-      HIPCHECK(hipEventRecord(ready, st));
-      HIPCHECK(hipStreamWaitEvent(st_rows, ready, 0));
-      sr = st_rows;
-    }
     if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
-      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, sr,
+      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st,
                          static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
                          static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
                          static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W, long(ldw), long(ncols));
-    }, sr);
+    }, st);
     if (rc) return rc;
   }
   return CWT_OK;
 }
 template <typename T>
-int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
-                hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
+int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   switch (p->rt->aols_logp) {
-    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, st_rows, ready);
+    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st);
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
 }
@@ -2082,15 +2025,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
 int cwt_plan_destroy(cwt_plan* p) {
   if (!p) return CWT_OK;
   (void)hipSetDevice(p->device);
-  pipe_drain(p);
   (void)hipStreamSynchronize(p->stream);
-  for (auto q : p->pq) if (q) (void)hipStreamDestroy(q);
-  for (auto r : p->pr) if (r) (void)hipStreamDestroy(r);
-  for (hipEvent_t e : {p->ev_in, p->ev_pfork, p->ev_xhat, p->ev_xs, p->ev_coef, p->ev_xsa}) if (e) (void)hipEventDestroy(e);
-  for (auto& L : p->lane) {
-    for (auto e : L.done) if (e) (void)hipEventDestroy(e);
-    for (void* b : {L.Z, L.xs, L.pcoef, L.pband, L.xm, L.xsa, L.hxhat}) if (b) (void)hipFree(b);
-  }
   for (int i = 0; i < 2; ++i) {
     if (p->side[i]) { (void)hipStreamSynchronize(p->side[i]); (void)hipStreamDestroy(p->side[i]); }
     if (p->ev_a[i]) (void)hipEventDestroy(p->ev_a[i]);
@@ -2124,7 +2059,6 @@ int cwt_plan_destroy(cwt_plan* p) {
 
 int cwt_plan_set_stream(cwt_plan* p, void* hip_stream) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
-  PIPE_SETTLE(p);
   HIPCHECK(hipStreamSynchronize(p->stream));
   p->stream = static_cast<hipStream_t>(hip_stream);
   return CWT_OK;
@@ -2132,7 +2066,6 @@ int cwt_plan_set_stream(cwt_plan* p, void* hip_stream) {
 
 int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   if (!p || !key) return fail(CWT_EINVAL, "plan/key is NULL");
-  PIPE_SETTLE(p);
   const std::string k(key);
   auto pow2 = [](int64_t v) { return v > 0 && (v & (v - 1)) == 0; };
   for (const char* gone : {"overlap", "pass_b_prefetch", "pass_b_small", "stamps", "ols_tile", "ols_fwd_real", "sched", "narrow_wave"})
@@ -2186,10 +2119,6 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
     if (value < 0 || value > 18) return fail(CWT_EINVAL, "tolerance_neglog10 in [0, 18]");
     p->tolerance = value ? std::pow(10.0, -double(value)) : 0.0;
   }
-  else if (k == "pipeline") p->pipeline = value != 0;
-  else if (k == "pipe_map") p->pipe_map = int(value);
-  else if (k == "pipe_one_lane") p->pipe_one_lane = value != 0;
-  else if (k == "pipe_prio") { if (p->pipe_ready) return fail(CWT_EINVAL, "pipe_prio must be set before the first pipelined call"); p->pipe_prio = value != 0; }
   else if (k == "big_terms") { if (value < 1 || value > 8) return fail(CWT_EINVAL, "big_terms in [1,8]"); p->big_terms = int(value); }
   else return fail(CWT_EINVAL, "unknown option " + k);
   return check_geometry(p);
@@ -2214,7 +2143,6 @@ int cwt_spectrum_range(cwt_plan* p, const void* xhat_dev, int64_t n, double* max
   if (!p || !xhat_dev || !max_abs || !rms_abs || !floor_abs) return fail(CWT_EINVAL, "NULL argument");
   if (n < 1) return fail(CWT_EINVAL, "n must be >= 1");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   constexpr int kOut = SPECTRUM_SLOTS, kGroupsMax = 512;
   if (!p->range_dev && hipMalloc(reinterpret_cast<void**>(&p->range_dev), size_t(kGroupsMax + 1) * kOut * sizeof(double)) != hipSuccess)
     return fail(CWT_ENOMEM, "device allocation failed");
@@ -2290,28 +2218,7 @@ int cwt_plan_get_tolerance(cwt_plan* p, double* rel_tol) {
 
 int cwt_plan_sync(cwt_plan* p) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
-  PIPE_SETTLE(p);
   HIPCHECK(hipStreamSynchronize(p->stream));
-  return CWT_OK;
-}
-
-int cwt_plan_join(cwt_plan* p) {
-  if (!p) return fail(CWT_EINVAL, "plan is NULL");
-  HIPCHECK(hipSetDevice(p->device));
-  return pipe_join(p);
-}
-
-int cwt_plan_set_input_stream(cwt_plan* p, void* hip_stream, int enable) {
-  if (!p) return fail(CWT_EINVAL, "plan is NULL");
-  PIPE_SETTLE(p);
-  p->in_stream = hip_stream;
-  p->in_stream_set = enable != 0;
-  return CWT_OK;
-}
-
-int cwt_plan_pipelined_calls(cwt_plan* p, int64_t* calls) {
-  if (!p || !calls) return fail(CWT_EINVAL, "NULL argument");
-  *calls = int64_t(p->pipe_calls);
   return CWT_OK;
 }
 
@@ -2329,7 +2236,6 @@ int cwt_free(int device, void* ptr) {
 int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
   HIPCHECK(hipStreamSynchronize(p->stream));
   return CWT_OK;
@@ -2337,7 +2243,6 @@ int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
 int cwt_memcpy_d2h(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return copy_d2h(p, dst, src, bytes);
 }
 
@@ -2345,7 +2250,6 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
                        : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
 }
@@ -2438,16 +2342,13 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   return CWT_OK;
 }
 
-std::vector<double> rows_key(int mother, double param, double dt, const double* scales, int nrows, bool have_signal, int64_t ncols) {
-  return call_key(0, {double(mother), param, dt, double(nrows), have_signal ? 1.0 : 0.0, double(ncols)}, {{scales, nrows}});
-}
-
 int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, double dt, const double* scales,
                        int nrows, int64_t ldw, int64_t ncols) {
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
-  const std::vector<double> key = rows_key(mother, param, dt, scales, nrows, have_signal, ncols);
+  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), have_signal ? 1.0 : 0.0, double(ncols)},
+                                           {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
     int rc = mother_constant(mother, param, &cre, &cim);
@@ -2485,166 +2386,6 @@ int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, 
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
 }
 
-// ---- pipelined mode ---------------------------------------------------------------------------------------------------
-int pipe_init(cwt_plan* p) {
-  if (p->pipe_ready) return CWT_OK;
-  int lo = 0, hi = 0;
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-  for (auto& q : p->pq)
-    HIPCHECK(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, p->pipe_prio ? hi : 0));   // hi = numerically lowest = highest priority
-  for (auto& r : p->pr) HIPCHECK(hipStreamCreateWithFlags(&r, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&p->ev_in, &p->ev_pfork, &p->ev_xhat, &p->ev_xs, &p->ev_coef, &p->ev_xsa})
-    HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  for (auto& L : p->lane)
-    for (auto& e : L.done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  p->pipe_ready = true;
-  return CWT_OK;
-}
-
-// The plan's stream waits for every row of every pipelined call queued so far: W (and the caller's spectrum) are complete
-// on the plan's stream from here on.
-int pipe_join(cwt_plan* p) {
-  if (!p->pipe_open) return CWT_OK;
-  for (auto& L : p->lane)
-    if (L.used)
-      for (auto e : L.done) HIPCHECK(hipStreamWaitEvent(p->stream, e, 0));
-  p->pipe_open = false;
-  p->pipe_rt = nullptr;
-  return CWT_OK;
-}
-
-// Blocks the host until the pipelined work has drained (error paths, destruction, stream changes).
-void pipe_drain(cwt_plan* p) {
-  if (!p->pipe_ready) return;
-  for (auto q : p->pq) if (q) (void)hipStreamSynchronize(q);
-  for (auto r : p->pr) if (r) (void)hipStreamSynchronize(r);
-  (void)hipGetLastError();
-  p->pipe_open = false;
-  p->pipe_rt = nullptr;
-}
-
-struct LaneGuard {     // the plan's scratch fields <-> the lane's, for the duration of one pipelined call
-  cwt_plan* p; cwt_plan::Lane& L;
-  LaneGuard(cwt_plan* plan, cwt_plan::Lane& lane) : p(plan), L(lane) { swap(); }
-  ~LaneGuard() { swap(); }
-  void swap() {
-    std::swap(p->Z, L.Z); std::swap(p->z_bytes, L.z_bytes);
-    std::swap(p->xs, L.xs); std::swap(p->xs_bytes, L.xs_bytes);
-    std::swap(p->pcoef, L.pcoef); std::swap(p->pcoef_bytes, L.pcoef_bytes);
-    std::swap(p->pband, L.pband); std::swap(p->pband_bytes, L.pband_bytes);
-    std::swap(p->xm, L.xm); std::swap(p->xm_bytes, L.xm_bytes);
-    std::swap(p->xsa, L.xsa); std::swap(p->xsa_bytes, L.xsa_bytes);
-    std::swap(p->hxhat, L.hxhat); std::swap(p->hxhat_bytes, L.hxhat_bytes);
-  }
-};
-
-// Which row tables the pipelined path takes: polynomial rows in one chunk, overlap-save rows, rows on the band-passed
-// signal; one signal; the default geometry.  Everything else joins and goes the ordinary way.
-bool pipe_applies(const cwt_plan* p) {
-  const cwt_plan::RowTable* rt = p->rt;
-  return p->pipeline && !p->profile && !p->graph && !rt->n_small && !rt->n_narrow && !rt->n_wide && rt->poly_chunks.size() <= 1 &&
-         rt->ols_nbatch == 1 && rt->aols_nbatch == 1 && (rt->n_poly + rt->n_ols + rt->n_aols) > 0 && check_geometry(p) == CWT_OK;
-}
-
-template <typename T>
-int transform_pipelined(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, void* xhat_user, void* W_dev,
-                        int64_t ldw, int64_t ncols) {
-  int rc = pipe_init(p);
-  if (rc) return rc;
-  const cwt_plan::RowTable* rt = p->rt;
-  if (p->pipe_open && (p->pipe_rt != static_cast<const void*>(rt) || p->pipe_build != rt->build_id)) {
-    rc = pipe_join(p);            // another row table: its rows may sit on other row streams than the same rows of W before
-    if (rc) return rc;
-  }
-  cwt_plan::Lane& L = p->lane[p->lane_turn];
-  if (!p->pipe_one_lane) p->lane_turn ^= 1;        // (pipe_one_lane: timing experiment only -- calls then share their scratch)
-  LaneGuard lane(p, L);
-  cplx<T>* W = static_cast<cplx<T>*>(W_dev);
-  hipStream_t pr_all[3] = {p->pr[0], p->pr[1], p->pr[2]};
-  if (p->pipe_map == 2) pr_all[1] = pr_all[2] = p->pr[0];     // pipe_map 2: every row kernel on ONE stream (overlap-save, band-passed, polynomial), prep as in 0
-  hipStream_t* pr = pr_all;
-  // pipe_map 0: the preparation on streams of its own (every prep kernel may run beside any row kernel);
-  // pipe_map 1: three in-order chains, one per row form -- [block spectra, overlap-save rows], [forward FFT, band-passed
-  //             signal, its rows], [bands, coefficients, polynomial rows] -- the preparation of a form follows the previous
-  //             call's rows of the same form on the same stream (the stagger of the one-call schedule, no extra queues)
-  hipStream_t pq_sep[3] = {p->pq[0], p->pq[1], p->pq[2]};
-  hipStream_t pq_chain[3] = {pr[2], pr[1], pr[2]};
-  hipStream_t* pq = p->pipe_map == 1 ? pq_chain : pq_sep;
-  hipStream_t poly_prep = p->pipe_map == 1 ? pr[0] : pq[0];
-  const bool need_xhat = rt->n_poly || rt->n_aols || xhat_user;
-  // buffers first (growing one synchronises the device; happens in the first calls only)
-  if (rt->n_ols) rc = grow(&p->xs, &p->xs_bytes, size_t(rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
-  if (!rc && need_xhat) rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * sizeof(cplx<T>), p->stream);
-  if (rc) return rc;
-  hipStream_t in = p->in_stream_set ? static_cast<hipStream_t>(p->in_stream) : p->stream;
-  HIPCHECK(hipEventRecord(p->ev_in, in));
-  if (!p->pipe_open) {
-    // first pipelined call since the last join: everything behind what the plan's stream holds (row-table upload, filter
-    // tables, the caller's earlier use of W)
-    HIPCHECK(hipEventRecord(p->ev_pfork, p->stream));
-    for (int i = 0; i < 3; ++i) {
-      HIPCHECK(hipStreamWaitEvent(pq[i], p->ev_pfork, 0));
-      HIPCHECK(hipStreamWaitEvent(pr[i], p->ev_pfork, 0));
-    }
-    p->pipe_open = true;
-    p->pipe_rt = rt;
-    p->pipe_build = rt->build_id;
-  }
-  for (int i = 0; i < 2; ++i) {                             // (prep stream 2 starts behind the spectrum of stream 0)
-    HIPCHECK(hipStreamWaitEvent(pq[i], p->ev_in, 0));
-    if (L.used)
-      for (auto e : L.done) HIPCHECK(hipStreamWaitEvent(pq[i], e, 0));     // this lane's scratch is free again
-  }
-  const void* xhat = p->hxhat;
-  // preparation
-  if (rt->n_ols) {
-    rc = launch_ols_fwd<T>(p, x_dev, n0, pq[1]);
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_xs, pq[1]));
-  }
-  if (need_xhat) {
-    {
-      StreamGuard guard(p);
-      p->stream = pq[0];
-      rc = fft_rows_impl<T, IN_REAL>(p, x_dev, 0, 1, n0, p->hxhat);
-    }
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_xhat, pq[0]));
-  }
-  if (rt->n_poly) {
-    if (poly_prep != pq[0]) {
-      HIPCHECK(hipStreamWaitEvent(poly_prep, p->ev_xhat, 0));
-      if (L.used) for (auto e : L.done) HIPCHECK(hipStreamWaitEvent(poly_prep, e, 0));
-    }
-    rc = launch_poly_coef<T>(p, static_cast<const cplx<T>*>(xhat), mo, 0, poly_prep, nullptr);
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_coef, poly_prep));
-  }
-  // rows, each kind on its own stream in call order
-  if (rt->n_ols) {
-    HIPCHECK(hipStreamWaitEvent(pr[1], p->ev_xs, 0));
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, pr[1]);
-    if (rc) return rc;
-  }
-  if (need_xhat) HIPCHECK(hipStreamWaitEvent(pr[2], p->ev_xhat, 0));
-  if (xhat_user)
-    HIPCHECK(hipMemcpyAsync(xhat_user, p->hxhat, size_t(p->N) * sizeof(cplx<T>), hipMemcpyDeviceToDevice, pr[2]));
-  if (rt->n_aols) {
-    HIPCHECK(hipStreamWaitEvent(pq[2], p->ev_xhat, 0));
-    rc = pq[2] == pr[2] ? launch_aols<T>(p, xhat, W, ldw, ncols, pr[2]) : launch_aols<T>(p, xhat, W, ldw, ncols, pq[2], pr[2], p->ev_xsa);
-    if (rc) return rc;
-  }
-  if (rt->n_poly) {
-    HIPCHECK(hipStreamWaitEvent(pr[0], p->ev_coef, 0));
-    rc = launch_poly_rows<T>(p, 0, W, ldw, ncols, pr[0]);
-    if (rc) return rc;
-  }
-  for (int i = 0; i < 3; ++i) HIPCHECK(hipEventRecord(L.done[i], pr[i]));
-  L.used = true;
-  ++p->pipe_calls;
-  return CWT_OK;
-}
-
 // The overlap-save rows need the signal only: cwt_transform queues them on side stream 1 BEFORE the forward FFT, so
 // that they run beside it and beside the two-pass chain; rows_impl then skips them and joins the stream at its end.
 template <typename T>
@@ -2666,7 +2407,6 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
                        const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
   if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return transform_rows_common(p, xhat_dev, nullptr, 0, mother, param, dt, scales, nrows, W_dev, ldw, ncols);
 }
 
@@ -2675,32 +2415,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   if (!p || !x_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  int rc = CWT_OK;
-  if (p->pipe_open) {
-    // a call that rebuilds a row table overwrites a slot whose rows kernels in flight may still read: drain first
-    const std::vector<double> key = rows_key(mother, param, dt, scales, nrows, true, ncols);
-    bool hit = false;
-    for (const auto& t : p->slots) hit = hit || t.key == key;
-    if (!hit || !p->pipeline) {
-      rc = pipe_join(p);
-      if (!rc && !hit) HIPCHECK(hipStreamSynchronize(p->stream));
-      if (rc) return rc;
-    }
-  }
-  rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
-  if (rc) return rc;
-  if (pipe_applies(p)) {
-    const Mother pmo = mother_of(mother, param);
-    rc = p->prec == 64 ? transform_pipelined<double>(p, x_dev, n0, pmo, xhat_dev, W_dev, ldw, ncols)
-                       : transform_pipelined<float>(p, x_dev, n0, pmo, xhat_dev, W_dev, ldw, ncols);
-    if (rc) {
-      const std::string msg = g_err;
-      pipe_drain(p);
-      g_err = msg;
-    }
-    return rc;
-  }
-  rc = pipe_join(p);
+  int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
   const bool only_ols = !xhat_dev && p->rt->n_ols == nrows;      // every row is an overlap-save row on the real signal
@@ -2783,7 +2498,6 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   const int total = nbatch * nrows;
   const std::vector<double> key = call_key(2, {double(mother), param, dt, double(nbatch), double(xhat_ld), double(nrows)},
                                            {{scales, nrows}});
@@ -2823,7 +2537,6 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   const int total = nbatch * nrows;
   const std::vector<double> key = call_key(3, {double(mother), param, dt, double(nbatch), double(nrows), double(ncols)},
                                            {{scales, nrows}});
@@ -2869,7 +2582,6 @@ int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* tabl
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   select_table(p, {});                                   // explicit filter banks are not cached
   std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
   int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
@@ -2888,7 +2600,6 @@ int cwt_fft_rows(cwt_plan* p, const void* in_dev, int in_complex, int nrows, int
   if (nrows < 1) return fail(CWT_EINVAL, "nrows must be >= 1");
   if (ncols_in < 1 || ncols_in > p->N || in_ld < ncols_in) return fail(CWT_EINVAL, "need 1 <= ncols_in <= nfft and in_ld >= ncols_in");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   if (p->prec == 64)
     return in_complex ? fft_rows_impl<double, IN_CPLX>(p, in_dev, in_ld, nrows, ncols_in, spec_dev)
                       : fft_rows_impl<double, IN_REAL>(p, in_dev, in_ld, nrows, ncols_in, spec_dev);
@@ -2904,7 +2615,6 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (spec_ld != 0 && spec_ld < p->N) return fail(CWT_EINVAL, "spec_ld must be 0 (shared) or >= nfft");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   const std::vector<double> key = call_key(1, {double(mother), param, double(spec_ld), double(nrows)},
                                            {{a, nrows}, {amp_re, nrows}, {amp_im, nrows}});
   if (!select_table(p, key)) {
@@ -2990,7 +2700,6 @@ int cwt_wct_products(cwt_plan* p, const void* W1_dev, const void* W2_dev, const 
   if (!p || !W1_dev || !W2_dev || !scales || !P_dev || !C_dev || !angle_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || nrows > p->max_rows || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? wct_products_impl<double>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev)
                        : wct_products_impl<float>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev);
 }
@@ -3000,7 +2709,6 @@ int cwt_cross_spectrum(cwt_plan* p, const void* W1_dev, const void* W2_dev, int 
   if (!p || !W1_dev || !W2_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || nrows > 65535 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   const dim3 grid(unsigned((ncols + 255) / 256), unsigned(nrows));
   return timed_launch(p, KC_ELEMENTWISE, [&] {
     if (p->prec == 64)
@@ -3018,7 +2726,6 @@ int cwt_boxcar_scales(cwt_plan* p, const void* in_dev, int nrows, int64_t ld, in
   if (nrows < 1 || ncols < 1 || ld < ncols || nwin < 1 || nwin > p->max_rows) return fail(CWT_EINVAL, "bad shape");
   if (in_dev == out_dev) return fail(CWT_EINVAL, "boxcar cannot run in place");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? boxcar_impl<double>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev)
                        : boxcar_impl<float>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev);
 }
@@ -3028,7 +2735,6 @@ int cwt_wct_coherence(cwt_plan* p, const void* S_dev, const void* S12_dev, int n
   if (!p || !S_dev || !S12_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? coherence_impl<double>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev)
                        : coherence_impl<float>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev);
 }
@@ -3056,7 +2762,6 @@ int cwt_reduce_scales(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "need ncols >= 1 and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   if (p->prec == 64)
     return power ? reduce_scales_impl<double, true>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev)
                  : reduce_scales_impl<double, false>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev);
@@ -3080,7 +2785,6 @@ int cwt_time_mean_power(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t nco
   if (!p || !W_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   if (p->prec == 64)
     return timed_launch(p, KC_ICWT, [&] {
       hipLaunchKernelGGL((k_time_mean<double>), dim3(nrows), dim3(256), 256 * sizeof(double), p->stream,
@@ -3098,7 +2802,6 @@ int cwt_coherence_histogram(cwt_plan* p, const void* r2_dev, int64_t ld, int nro
   if (nrows < 1 || ld < 1 || nbins < 1 || nbins > 16384 || max_span < 0) return fail(CWT_EINVAL, "bad shape");
   if (max_span == 0) return CWT_OK;
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   static_assert(sizeof(long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "LP64 expected");
   const unsigned gx = unsigned(std::min<int64_t>(512, (max_span + 4095) / 4096));   // >= 16 columns per thread
   const size_t lds = size_t(nbins) * sizeof(unsigned);
@@ -3225,7 +2928,6 @@ int transform_rows_n_impl(cwt_plan* p, const void* xhat_dev, int64_t n0, int mot
 int cwt_forward_fft_n(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? forward_fft_n_impl<double>(p, x_dev, n0, xhat_dev) : forward_fft_n_impl<float>(p, x_dev, n0, xhat_dev);
 }
 
@@ -3237,7 +2939,6 @@ int cwt_transform_rows_n(cwt_plan* p, const void* xhat_dev, int64_t n0, int moth
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   if (mother < MOTHER_MORLET || mother > MOTHER_DOG) return fail(CWT_EINVAL, "unknown mother id");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   return p->prec == 64 ? transform_rows_n_impl<double>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw)
                        : transform_rows_n_impl<float>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw);
 }
@@ -3287,7 +2988,6 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!p || !x_host || !scales) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   const size_t es = p->esize();
   // A transform that fits one workgroup per row (the reference's canonical 504-point call: 4 KB in, 0.8 MB out) is all
   // latency, and copy operations are the larger part of it.  Here it has none: the forward FFT reads the signal from the
@@ -3358,7 +3058,6 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   }
   if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);
   else rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);
-  if (!rc) rc = pipe_join(p);                              // (option "pipeline": the copies below run on the plan's stream)
   if (rc) return rc;
   if (staged) {
     if (xh_b) HIPCHECK(hipMemcpyAsync(stage + in_b, p->hxhat, xh_b, hipMemcpyDeviceToHost, p->stream));
@@ -3427,7 +3126,6 @@ int cwt_plan_classify(cwt_plan* p, int mother, double param, double dt, const do
                       int with_signal, int* codes) {
   if (!p || !scales || !codes) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  PIPE_SETTLE(p);
   int rc = prepare_rows_table(p, with_signal != 0, mother, param, dt, scales, nrows, ncols, ncols);
   if (rc) return rc;
   int n = 0;

@@ -50,7 +50,7 @@ def test_single_rank_line_has_parity_and_cpu_baseline(emu_library, tmp_path):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert d["cpu_baseline"]["value"] > 0 and isinstance(d["cpu_baseline"]["reference_mounted"], bool)
     assert full["cpu_baseline"]["reference_as_is"]["kind"] in ("reference", "port")
-    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "per_class" in full["roofline"]
+    assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "per_class" in full["roofline"]
     assert "per_class" not in d["roofline"] and "kernels" not in d["roofline"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12

@@ -1010,90 +1010,3 @@ def test_polynomial_rows_in_chunks_at_full_size(hip_library):
             b.free()
         plan.close()
     assert np.array_equal(out[96], out[0]) and np.array_equal(out[24], out[0])
-
-
-@pytest.mark.parametrize("name,prec", [("morlet", 64), ("dog", 32)])
-def test_pipelined_calls_keep_every_bit_of_the_ordinary_calls(hip_library, name, prec):
-    """Option "pipeline" (cwt_plan_join): the preparation of call c + 1 runs beside the rows of call c on other streams, every
-    scratch buffer exists twice.  Seven different signals back to back, each into its own W: every bit of every W and of every
-    spectrum equals what the same plan options give one call at a time -- a race between a call's preparation and the rows of
-    its neighbours (block spectra, coefficient planes, band-passed signal, spectrum) would show as a wrong block of some row."""
-    N = 1 << 20
-    kind, param = MOTHERS[name]
-    m = orc.Mother(kind, param)
-    sj = grid(N, 1.0, m, 256)[:192:3]                       # 64 rows: overlap-save, band-passed and polynomial rows
-    cplx, es = (np.complex128, 16) if prec == 64 else (np.complex64, 8)
-    real = np.float64 if prec == 64 else np.float32
-    tol = 1e-9 if prec == 64 else 3e-5
-    K = 7
-    xs = [np.random.default_rng(100 + i).standard_normal(N).astype(real) * (1.0 + i) for i in range(K)]
-    plan = _hip.Plan(N, prec, max_rows=64, options={"tolerance": tol, "pipeline": 1})
-    xd = [_hip.DeviceBuffer(x.nbytes) for x in xs]
-    xh = [_hip.DeviceBuffer(N * es) for _ in xs]
-    Wd = [_hip.DeviceBuffer(len(sj) * N * es) for _ in xs]
-    for b, x in zip(xd, xs):
-        b.upload(plan, x)
-    for rep in range(2):                                    # (the first round also grows the lanes' buffers)
-        for i in range(K):
-            plan.transform(xd[i].ptr, N, kind, float(param), 1.0, sj, xh[i].ptr, Wd[i].ptr, N, N)
-    assert plan.pipelined_calls() == 2 * K, plan.row_classes()
-    plan.join()
-    split = plan.last_split()
-    assert split["ols"] >= 4 and split["poly"] >= 8, split
-    ref = _hip.Plan(N, prec, max_rows=64, options={"tolerance": tol})
-    rh, rW = _hip.DeviceBuffer(N * es), _hip.DeviceBuffer(len(sj) * N * es)
-    for i in range(K):
-        ref.transform(xd[i].ptr, N, kind, float(param), 1.0, sj, rh.ptr, rW.ptr, N, N)
-        want = rW.download(ref, (len(sj), N), cplx)
-        got = Wd[i].download(plan, (len(sj), N), cplx)
-        bad = np.flatnonzero((got != want).any(axis=1))
-        assert bad.size == 0, (i, bad[:8])
-        assert np.array_equal(xh[i].download(plan, (N,), cplx), rh.download(ref, (N,), cplx)), i
-    idx = [0, 21, 42, 63]
-    per_row, _ = row_errors(got[idx], orc.cwt_rows(xs[-1].astype(np.float64), 1.0, sj[idx], m))
-    assert per_row.max() < (1e-8 if prec == 64 else 1e-4)
-    # the same W for consecutive calls: rows are written in call order, the last signal's transform stays
-    for i in range(K):
-        plan.transform(xd[i].ptr, N, kind, float(param), 1.0, sj, xh[0].ptr, Wd[0].ptr, N, N)
-    out = _hip.DeviceBuffer(N * (8 if prec == 64 else 4))
-    plan.icwt_reduce(Wd[0].ptr, N, N, sj, 1.0, out.ptr)      # another entry point: joins first
-    assert np.array_equal(Wd[0].download(plan, (len(sj), N), cplx), want)
-    for b in xd + xh + Wd + [rh, rW, out]:
-        b.free()
-    plan.close()
-    ref.close()
-
-
-def test_pipelined_calls_with_the_signal_on_another_stream(hip_library):
-    """cwt_plan_set_input_stream: the signal arrives on a stream of its own (an upload, a collective); the preparation waits for
-    that stream, not for the plan's."""
-    import torch
-    N = 1 << 20
-    m = orc.Mother(orc.MORLET, 6)
-    sj = grid(N, 1.0, m, 256)[:128:2]
-    dev = torch.device("cuda", 0)
-    feed = torch.cuda.Stream(device=dev)
-    plan = _hip.Plan(N, 64, max_rows=64, options={"tolerance": 1e-9, "pipeline": 1})
-    plan.set_stream(torch.cuda.current_stream().cuda_stream)
-    plan.set_input_stream(feed.cuda_stream, True)
-    K = 5
-    host = [torch.from_numpy(np.random.default_rng(200 + i).standard_normal(N)).pin_memory() for i in range(K)]
-    xdev = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(K)]
-    W = [torch.empty((len(sj), N), dtype=torch.complex128, device=dev) for _ in range(K)]
-    xh = torch.empty(N, dtype=torch.complex128, device=dev)
-    for i in range(K):
-        with torch.cuda.stream(feed):
-            xdev[i].copy_(host[i], non_blocking=True)       # the signal becomes ready on `feed`
-        plan.transform(xdev[i].data_ptr(), N, orc.MORLET, 6.0, 1.0, sj, xh.data_ptr(), W[i].data_ptr(), N, N)
-    plan.join()
-    torch.cuda.synchronize()
-    assert plan.pipelined_calls() == K
-    ref = _hip.Plan(N, 64, max_rows=64, options={"tolerance": 1e-9})
-    ref.set_stream(torch.cuda.current_stream().cuda_stream)
-    Wr = torch.empty_like(W[0])
-    for i in range(K):
-        ref.transform(xdev[i].data_ptr(), N, orc.MORLET, 6.0, 1.0, sj, xh.data_ptr(), Wr.data_ptr(), N, N)
-        torch.cuda.synchronize()
-        assert torch.equal(W[i], Wr), i
-    plan.close()
-    ref.close()
