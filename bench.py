@@ -742,7 +742,8 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
         out["effective_warmup_steps"] = args.warmup
     traffic = None
     if (args.live_traffic and not args.emulate and not wl.sharded and not rt.use_dist and not args.shard and want_cpu
-            and set(wl.opts) <= {"tolerance"} and config == args.config and wl.tolerance == BENCH_TOLERANCE[wl.prec]):
+            and set(wl.opts) <= {"tolerance"} and wl.tolerance == BENCH_TOLERANCE[wl.prec]):
+        # (the config-3 blocks of the default run too: round 4 read theirs from committed files)
         split = wl.plan.last_split()
         traffic = live_traffic(config, args.logn, rows_total, split.get("poly", 0), wl.csize)
     if not wl.sharded and not rt.use_dist and not args.emulate:

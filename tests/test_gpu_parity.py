@@ -505,12 +505,15 @@ def _download_rows(plan, buf, lo, cnt, ld, dtype):
 
 
 @pytest.mark.parametrize("target", ["round-off", "bench"])
-@pytest.mark.parametrize("name,prec", [("morlet", 64), ("paul", 32), ("dog", 32)])
+@pytest.mark.parametrize("name,prec", [("morlet", 64), ("paul", 32), ("dog", 32), ("paul", 64), ("dog", 64)])
 def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, prec, target):
     """BASELINE configs 2 and 3 exactly as bench.py times them -- N = 2^20, all 256 rows, device resident, through
     cwt_transform (forward FFT + rows, every row form) -- with EVERY row compared with the oracle (pycwt/wavelet.py:91-106
     restated), in slabs of 16 rows.  Prints the worst row per kernel class.  Rows the reference turns into NaN
-    (Paul: 161 of 256, wavelet.py:111-115) are computed too and must be finite; they have no reference value.
+    (Paul: 161 of 256, wavelet.py:111-115) have no reference value: they are compared with the "intended value" oracle
+    (cwt_rows(..., intended=True): Heaviside before the exponential, identical to the reference on the rows it keeps).
+    ("paul", 64) and ("dog", 64) are not BASELINE configs (config 3 is quoted in fp32) but the reference's own arithmetic
+    for those mothers (mothers.py:118-122, 170-173 yield complex128) and what `pycwt_amd.cwt(..., 'paul')` runs by default.
     target "round-off": every truncation below the arithmetic's rounding (the suite's setting); "bench": the accuracy target
     bench.py times (bench.BENCH_TOLERANCE), i.e. the SAME row classification as the headline, against bench.py's own bar."""
     import bench
@@ -530,29 +533,32 @@ def test_every_row_of_the_bench_workloads_against_the_oracle(hip_library, name, 
     plan.transform(xd.ptr, N, kind, param, 1.0, sj, xh.ptr, Wd.ptr, N, N)
     classes = plan.row_classes()
     assert len(classes) == rows
-    assert any(c.startswith("ols/") for c in classes) and any(c.startswith("poly/") for c in classes)
-    if name != "dog":
+    assert any(c.startswith("poly/") for c in classes)
+    if not (name == "paul" and prec == 64):          # (fp64 Paul at round-off: the 1/t^5 tail leaves no row a halo that fits a tile)
+        assert any(c.startswith("ols/") for c in classes)
+    if name != "dog" and prec == 32 or name == "morlet":
         assert any(c.startswith("aols/") for c in classes)
     dropped = orc.dropped_rows(sj, 1.0, m)
-    worst, checked = {}, 0
+    worst, checked, n_intended = {}, 0, 0
     for lo in range(0, rows, 16):
         got = _download_rows(plan, Wd, lo, 16, N, cplx)
         assert np.isfinite(got.view(real)).all()
         with np.errstate(all="ignore"):
-            ref = orc.cwt_rows(x, 1.0, sj[lo:lo + 16], m)
+            ref = orc.cwt_rows(x, 1.0, sj[lo:lo + 16], m, intended=True)
         for k in range(16):
             j = lo + k
-            if dropped[j]:
-                continue
             err = np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max()
-            checked += 1
+            checked += not dropped[j]
+            if dropped[j]:
+                n_intended += 1
             if err >= worst.get(classes[j], (0.0, -1))[0]:
                 worst[classes[j]] = (float(err), j)
     plan_tol = plan.tolerance()
     for b in (xd, xh, Wd):
         b.free()
     plan.close()
-    print(f"{name} fp{prec} ({target}, tolerance {plan_tol:g}): {checked} rows compared; worst row per kernel class:")
+    print(f"{name} fp{prec} ({target}, tolerance {plan_tol:g}): {checked} rows compared with the reference's arithmetic, "
+          f"{n_intended} (rows the reference drops) with the intended-value oracle; worst row per kernel class:")
     for c in sorted(worst):
         print(f"   {c:22s} row {worst[c][1]:3d}  err {worst[c][0]:.3e}")
     assert checked == rows - int(dropped.sum()) and checked >= 90      # Paul: 95 rows survive the reference's NaN rule
@@ -589,16 +595,26 @@ def test_config4_full_batch_sampled_pairs(hip_library):
             pairs.add((int(i) // rows, int(i) % rows))
     while len(pairs) < 48:
         pairs.add((int(rng.integers(nb)), int(rng.integers(rows))))
-    worst = 0.0
+    # ... and 512 more drawn with a FRESH seed every run (printed, so that a failure can be replayed with CWT_TEST_SEED):
+    # unlike Parseval on all rows (test_config4_full_batch_parseval_on_every_row) a sampled row sees a phase error
+    import os
+    seed = int(os.environ.get("CWT_TEST_SEED", np.random.SeedSequence().entropy % (1 << 32)))
+    fresh = np.random.default_rng(seed)
+    print(f"config 4 fresh pairs: CWT_TEST_SEED={seed}")
+    while len(pairs) < 48 + 512:
+        pairs.add((int(fresh.integers(nb)), int(fresh.integers(rows))))
+    worst, where = 0.0, None
     for b, j in sorted(pairs):
         got = _download_rows(plan, Wd, b * rows + j, 1, N, np.complex128)[0]
         ref = orc.cwt_rows(X[b], 1.0, sj[j:j + 1], m)[0]
-        worst = max(worst, np.abs(got - ref).max() / np.abs(ref).max())
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        if err > worst:
+            worst, where = err, (b, j, classes[b * rows + j])
     for buf in (xd, xh, Wd):
         buf.free()
     plan.close()
-    print(f"config 4 full batch: {len(pairs)} (signal, scale) pairs, worst row error {worst:.3e}")
-    assert worst < TOL[64]
+    print(f"config 4 full batch: {len(pairs)} (signal, scale) pairs, worst row error {worst:.3e} at {where}")
+    assert worst < TOL[64], (seed, where, worst)
 
 
 @pytest.mark.parametrize("precision,tol", [(64, 1e-11), (32, 2e-4)])
@@ -839,10 +855,13 @@ def test_round4_row_forms_against_the_forms_they_replace(hip_library, name, prec
     per_row, _ = row_errors(Wn, Wo)
     assert per_row.max() < TOL[prec], (per_row.argmax(), cn[per_row.argmax()], co[per_row.argmax()], per_row.max())
     dropped = orc.dropped_rows(sj, 1.0, m)
-    pick = [i for i in (list(np.flatnonzero([c.startswith("aols") for c in cn])[:3]) +
-                        list(np.flatnonzero([c.startswith("poly") for c in cn])[::12])) if not dropped[i]]
+    # (rows the reference turns into NaN included: the intended-value oracle has them)
+    pick = (list(np.flatnonzero([c.startswith("aols") for c in cn])[:3]) +
+            list(np.flatnonzero([c.startswith("poly") for c in cn])[::12]))
+    if name == "paul":
+        assert dropped[pick].any()
     with np.errstate(all="ignore"):
-        ref = orc.cwt_rows(x, 1.0, sj[pick], m, N=N)[:, :n0]
+        ref = orc.cwt_rows(x, 1.0, sj[pick], m, N=N, intended=True)[:, :n0]
     per_row, _ = row_errors(Wn[pick], ref)
     assert per_row.max() < TOL[prec], (per_row, [cn[i] for i in pick])
 
@@ -1002,10 +1021,13 @@ def test_polynomial_rows_in_chunks_at_full_size(hip_library):
             ref = Wo.download(old, (len(pick), N), np.complex128)
             Wo.free()
             old.close()
+            want = orc.cwt_rows(x, 1.0, sj[pick], m, intended=True)     # these scales are rows the reference drops
+            assert (sj[pick] * np.pi > 709.7827).all()            # (SURVEY 8a quirk iii: exp(-f) overflows at the Nyquist bin)
             for i, k in enumerate(pick):
                 got = _download_rows(plan, Wd, k, 1, N, np.complex128)[0]
                 assert np.isfinite(got.view(np.float64)).all()
                 assert np.abs(got - ref[i]).max() < 1e-8 * np.abs(ref[i]).max()
+                assert np.abs(got - want[i]).max() < 1e-8 * np.abs(want[i]).max()
         for b in (xd, xh, Wd):
             b.free()
         plan.close()

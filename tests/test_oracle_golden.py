@@ -165,3 +165,36 @@ def test_reference_sample_datasets(name):
         np.testing.assert_allclose(a, b, rtol=1e-14)
     np.testing.assert_allclose(fft, g["fft"], rtol=0, atol=1e-13 * np.abs(g["fft"]).max())
     np.testing.assert_allclose(orc.icwt(W, sj, float(g["dt"]), 1 / 12, orc.Mother(orc.MORLET, 6)), g["icwt"], rtol=1e-12, atol=1e-13)
+
+
+def test_intended_value_oracle_equals_the_reference_arithmetic_where_the_reference_is_finite():
+    """oracle.cwt_rows(..., intended=True): Paul's Heaviside applied before the exponential (SURVEY.md 8a quirk iii) -- the
+    value the GPU computes on the rows the reference turns into NaN.  On every row the reference KEEPS it must be the
+    reference's own arithmetic bit for bit; on the dropped rows it must be finite and continue the kept rows smoothly
+    (row energy against the neighbouring kept row: Parseval on the filter)."""
+    n = 4096
+    x = np.random.default_rng(17).standard_normal(n)
+    m = orc.Mother(orc.PAUL, 4)
+    s0 = 2 / m.flambda()
+    sj = s0 * 2 ** (np.arange(64) * np.log2(n / s0) / 63)
+    dropped = orc.dropped_rows(sj, 1.0, m)
+    assert dropped.any() and not dropped.all()
+    with np.errstate(all="ignore"):
+        ref = orc.cwt_rows(x, 1.0, sj, m)
+    want = orc.cwt_rows(x, 1.0, sj, m, intended=True)
+    assert np.array_equal(ref[~dropped], want[~dropped])
+    assert np.isnan(ref[dropped]).all() and np.isfinite(want[dropped]).all()
+    # independent check of the dropped rows: direct sum over the positive bins with the filter written out
+    k = np.arange(1, n // 2)
+    xh = np.fft.fft(x)
+    c = 2.0 ** 4 / np.sqrt(4 * 5040.0)
+    for j in np.flatnonzero(dropped)[[0, -1]]:
+        f = sj[j] * 2 * np.pi * k / n
+        F = np.sqrt(sj[j] * 2 * np.pi / n * n) * c * f ** 4 * np.exp(-f)
+        row = np.zeros(n, complex)
+        row[1:n // 2] = xh[1:n // 2] * F
+        direct = np.fft.ifft(row)
+        assert np.abs(direct - want[j]).max() <= 1e-12 * np.abs(direct).max()
+    for kind, p in ((orc.MORLET, 6), (orc.DOG, 2)):                        # other mothers: the flag changes nothing
+        mo = orc.Mother(kind, p)
+        assert np.array_equal(orc.cwt_rows(x, 1.0, sj[:8], mo), orc.cwt_rows(x, 1.0, sj[:8], mo, intended=True))
