@@ -205,6 +205,9 @@ struct cwt_plan {
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
+  int ols_fwd_split = 0;   // (transient) the two tile sizes' block spectra went to two streams
+  int ols_order = 0;       // option: 1 = the default-tile rows before the half-size-tile rows
+  int ols_split = 1;       // option: block spectra of the two tile sizes side by side on two streams (cwt_transform, ols_early)
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
@@ -1515,13 +1518,16 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
                        long(p->ols_x_ld), p->rt->ols_xs_sig);
   }, st);
 }
+// st1 != nullptr: the block spectra of the default-tile rows (group 1) on that stream, beside those of the half-size tiles,
+// and `ready1` recorded behind them -- the half-size-tile rows, by far the longer launch, then wait for their own spectra only.
 template <typename T>
-int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st0, hipStream_t st1 = nullptr, hipEvent_t ready1 = nullptr) {
   int rc = CWT_OK;
   {
     for (int g = 0; g < 2 && !rc; ++g) {
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows) continue;
+      hipStream_t st = (g == 1 && st1) ? st1 : st0;
       for (int d = 0; d < 3 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
@@ -1533,6 +1539,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
         }
       }
     }
+    if (!rc && st1 && ready1) HIPCHECK(hipEventRecord(ready1, st1));
     return rc;
   }
 }
@@ -1552,12 +1559,14 @@ int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, hipEvent_t ready1 = nullptr) {
   int rc = CWT_OK;
-  for (int g = 0; g < 2 && !rc; ++g) {        // the half-size tiles first (by far the longer launch since the rows with long
+  for (int gi = 0; gi < 2 && !rc; ++gi) {     // the half-size tiles first (by far the longer launch since the rows with long
                                               // halos went to the polynomial form), then the default tile's rows
+    const int g = p->ols_order ? 1 - gi : gi; // (option ols_order = 1: the few default-tile rows first)
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows) continue;
+    if (g == 1 && ready1) HIPCHECK(hipStreamWaitEvent(st, ready1, 0));     // their block spectra came on another stream
     switch (G.logp) {
       case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
       case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
@@ -1775,7 +1784,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     if (rc) return rc;
   }
   if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1]);
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1], p->ols_fwd_split ? p->ev_b[0] : nullptr);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
@@ -2113,6 +2122,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
+  else if (k == "ols_split") p->ols_split = value != 0;
+  else if (k == "ols_order") p->ols_order = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "tolerance_neglog10") {   // integer alias of cwt_plan_set_tolerance for option sweeps: 10^-value; 0 = default
@@ -2394,7 +2405,10 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
-  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
+  p->ols_fwd_split = p->ols_split && p->rt->ols_grp[0].nrows && p->rt->ols_grp[1].nrows;
+  if (p->ols_fwd_split) HIPCHECK(hipStreamWaitEvent(p->side2, p->ev_fork, 0));
+  rc = p->ols_fwd_split ? launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->side2, p->ev_b[0])
+                        : launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
   if (rc) return rc;                                    // polynomial rows)
   (void)W_dev; (void)ldw; (void)ncols;
   p->ols_launched = 1;
@@ -2426,7 +2440,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   }
   const Mother mo = mother_of(mother, param);
   auto enqueue = [&]() -> int {
-    p->ols_launched = 0;
+    p->ols_launched = 0; p->ols_fwd_split = 0;
     int r = CWT_OK;
     if (only_ols)
       return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
@@ -2440,7 +2454,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
                       : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
     if (!r) r = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                               : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
-    p->ols_launched = 0;
+    p->ols_launched = 0; p->ols_fwd_split = 0;
     return r;
   };
   if (!p->graph || p->profile) return enqueue();
@@ -2568,7 +2582,7 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
   int rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev)
                          : fft_rows_impl<float, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev);
   if (rc) return rc;
-  p->ols_launched = 0;
+  p->ols_launched = 0; p->ols_fwd_split = 0;
   p->ols_x_ld = x_ld;
   rc = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0)
                      : rows_impl<float>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0);
