@@ -53,7 +53,7 @@ def test_single_rank_line_has_parity_and_cpu_baseline(emu_library, tmp_path):
     assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "per_class" in full["roofline"]
     assert "per_class" not in d["roofline"] and "kernels" not in d["roofline"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"] + 1e-12
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
