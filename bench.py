@@ -122,32 +122,6 @@ class Runtime:
     def stream_handle(self):
         return 0 if self.emulate else self.torch.cuda.current_stream().cuda_stream
 
-    def feed_stream(self):
-        """A second stream (the one the signal arrives on).  Rehearsal on CPU: a stand-in with the same interface, so that the
-        loop that uses it is the loop the GPU run executes."""
-        import contextlib
-        rt = self
-
-        class Feed:
-            def __init__(self):
-                self.s = None if rt.emulate else rt.torch.cuda.Stream(device=rt.dev)
-                self.handle = 0 if rt.emulate else self.s.cuda_stream
-
-            def context(self):
-                return contextlib.nullcontext() if rt.emulate else rt.torch.cuda.stream(self.s)
-
-            def wait_event(self, ev):
-                if ev is not None and not rt.emulate:
-                    self.s.wait_event(ev)
-        return Feed()
-
-    def record_event(self):
-        if self.emulate:
-            return None
-        ev = self.torch.cuda.Event()
-        ev.record()
-        return ev
-
     def sync(self):
         if not self.emulate:
             self.torch.cuda.synchronize()
@@ -174,7 +148,7 @@ class Workload:
     """One BASELINE configuration on this rank: the signal, this rank's rows (j = rank mod world) of a
     `rows_total`-row scale grid, the device buffers and the plan."""
 
-    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced", pipeline=1, input_stream=True):
+    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced", pipeline=1):
         from pycwt_amd import _hip
         torch = rt.torch
         self.rt, self.config = rt, config
@@ -203,20 +177,11 @@ class Workload:
         x = torch.empty(self.N, dtype=real_t, device=rt.dev)
         if rt.rank == 0:
             x.copy_(torch.from_numpy(self.x_host))
-        # signal buffers: the broadcast of step i+1 lands in another one while step i computes (three with the signal on a
-        # stream of its own: the preparation of step i+1 then runs while the rows of step i are still being written)
-        self.xbuf = [x, x.clone(), x.clone()]
+        # two signal buffers: the broadcast of step i+1 lands in the other one while step i computes
+        self.xbuf = [x, x.clone()]
         self.xhat = torch.empty(self.N, dtype=cplx_t, device=rt.dev)
         self.W = torch.empty((max(len(self.sj), 1), self.N), dtype=cplx_t, device=rt.dev)
         self.plan.set_stream(rt.stream_handle())
-        # The signal lives on a stream of its own (cwt_plan_set_input_stream): what a transform computes from the signal alone
-        # (forward FFT, block spectra, band-passed signal) does not queue behind the plan's stream, i.e. in this loop not behind
-        # the rows of the previous step.  `--no-input-stream`: the signal on the plan's stream (every step strictly after the last).
-        self.feed = None
-        if input_stream:
-            self.feed = rt.feed_stream()
-            self.plan.set_input_stream(self.feed.handle, True)
-            rt.sync()
         # --pipeline P > 1 (diagnostic): P signals in flight, step i on lane i mod P = its own plan, stream and W
         self.lanes = [(self.plan, None, self.W, self.xhat)]
         for _ in range(1, pipeline):
@@ -240,34 +205,12 @@ class Workload:
         wait for the broadcast, so host enqueue, xGMI transfer and kernels all overlap.  Every timed step owns
         exactly one broadcast: none is issued ahead of the region's start, none is prefetched past its end."""
         rt = self.rt
-        if self.feed is None:
-            pending = rt.dist.broadcast(self.xbuf[0], src=0, async_op=True) if rt.use_dist else None
-            for i in range(count):
-                if rt.use_dist:
-                    pending.wait()
-                    pending = rt.dist.broadcast(self.xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
-                self.compute(self.xbuf[i & 1], i)
-            return
-        # The signal on the feed stream: the broadcast is issued and awaited THERE (RCCL's stream synchronises with the stream
-        # that is current when a collective is issued / waited for), the transform is told so, and the plan's stream only ever
-        # holds the joins of the transforms.  Buffer (i+1) % 3 was last read by step i-2: the feed stream waits for that step's
-        # completion on the plan's stream (an event recorded behind its transform) before the broadcast may overwrite it.
-        feed = self.feed
-        done = [None, None, None]
-        with feed.context():
-            pending = rt.dist.broadcast(self.xbuf[0], src=0, async_op=True) if rt.use_dist else None
+        pending = rt.dist.broadcast(self.xbuf[0], src=0, async_op=True) if rt.use_dist else None
         for i in range(count):
             if rt.use_dist:
-                with feed.context():
-                    pending.wait()
-            self.compute(self.xbuf[i % 3], i)
-            if rt.use_dist:
-                done[i % 3] = rt.record_event()
-                if i + 1 < count:
-                    if done[(i + 1) % 3] is not None:
-                        feed.wait_event(done[(i + 1) % 3])
-                    with feed.context():
-                        pending = rt.dist.broadcast(self.xbuf[(i + 1) % 3], src=0, async_op=True)
+                pending.wait()
+                pending = rt.dist.broadcast(self.xbuf[(i + 1) & 1], src=0, async_op=True) if i + 1 < count else None
+            self.compute(self.xbuf[i & 1], i)
 
     def timed(self, steps, warmup):
         rt = self.rt
@@ -672,7 +615,6 @@ def live_traffic(config, logn, rows, n_poly, csize):
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "cwt", "--",
                    sys.executable, os.path.abspath(__file__), "--config", config, "--logn", str(logn), "--rows", str(rows),
                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-prime", "--no-live-traffic",
-                   "--no-input-stream",
                    "--opt", "overlap_narrow=0", "--opt", "ols_early=0", "--opt", "ols_side=0"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
@@ -725,7 +667,7 @@ def compact_line(out, detail_path):
     line = pick(out, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                       "vs_baseline", "dtype", "data"])
     line["config"] = pick(out["config"], ["workload", "N", "rows_total", "rows_per_gpu", "mother", "param", "tolerance",
-                                          "parallelism", "signal_stream", "plan_options", "shard_diagnostic", "signals_in_flight"])
+                                          "parallelism", "plan_options", "shard_diagnostic", "signals_in_flight"])
     if not line["config"].get("plan_options"):
         line["config"].pop("plan_options", None)
     roof = out.get("roofline") or {}
@@ -754,8 +696,6 @@ def compact_line(out, detail_path):
     short = {}
     if "c2_roundoff" in ex:
         short["c2_roundoff_ms"] = ex["c2_roundoff"]["ms_per_step"]
-    if "c2_sequential" in ex:
-        short["c2_sequential_ms"] = ex["c2_sequential"]["ms_per_step"]
     for c in ("c3_paul", "c3_dog", "paul64", "dog64"):
         if c in ex and "value" in ex[c]:
             short[c + "_gs"] = ex[c]["value"]
@@ -783,9 +723,8 @@ def compact_line(out, detail_path):
     return rnd(line)
 
 
-def measure(rt, config, args, rows_total, opts, want_cpu, input_stream=None):
-    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline,
-                  args.input_stream if input_stream is None else input_stream)
+def measure(rt, config, args, rows_total, opts, want_cpu):
+    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
     if args.prime and not args.emulate:
         # the same W + K steps first from an idle device (reported as `from_idle`), then with the clocks up (the headline)
         idle = wl.timed(args.steps, args.warmup)
@@ -859,9 +798,6 @@ def main():
     ap.add_argument("--no-prime", dest="prime", action="store_false",
                     help="do not bring the device to its sustained clocks before the W warm-up steps (then `value` is what "
                          "`from_idle` reports otherwise)")
-    ap.add_argument("--no-input-stream", dest="input_stream", action="store_false",
-                    help="keep the signal on the plan's own stream: every step strictly after the previous one "
-                         "(reported as `sequential` by the default run)")
     ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
                     help="do not measure the HBM traffic with rocprofv3 PMC passes inside this run (two short child runs)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
@@ -914,7 +850,6 @@ def main():
                    "tolerance": head["tolerance"],
                    "parallelism": (f"scale-sharded x{world}, 1 broadcast/step, backend {rt.backend}" if world > 1
                                    else "single GPU"),
-                   "signal_stream": "own stream (cwt_plan_set_input_stream)" if args.input_stream else "plan's stream",
                    "plan_options": opts, **({"shard_diagnostic": args.shard} if args.shard else {}),
                    **({"signals_in_flight": args.pipeline} if args.pipeline > 1 else {})},
         "roofline": head["roofline"],
@@ -944,12 +879,6 @@ def main():
                                        "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"], "tolerance": r["tolerance"],
                                        "whole_path_frac": r["roofline"].get("whole_path_frac"),
                                        "row_split": r["roofline"].get("row_split"), "from_idle": r.get("from_idle")}
-        if args.input_stream:
-            # the same workload with the signal on the plan's own stream: every step strictly behind the previous one
-            r = measure(rt, "c2", args, rows_total, opts, want_cpu=False, input_stream=False)
-            out["extra"]["c2_sequential"] = {"workload": workload + ", signal on the plan's stream (--no-input-stream)", "value": r["value"],
-                                             "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"],
-                                             "whole_path_frac": r["roofline"].get("whole_path_frac"), "from_idle": r.get("from_idle")}
         out["extra"]["c1_nino3_latency"] = config1_latency()
         out["extra"]["c4_batch"] = config4_batch(rt)
         out["extra"]["c5_xwt_wct"] = config5_callers()

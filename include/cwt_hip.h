@@ -156,19 +156,6 @@ int cwt_plan_auto_tolerance(cwt_plan* plan, const void* xhat_dev, double target,
 int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 /* Block the host until everything queued by this plan has finished. */
 int cwt_plan_sync(cwt_plan* plan);
-/* The signal on a stream of its own.  enable != 0: the x_dev of the following cwt_transform calls becomes ready on
- * `hip_stream` (the stream an upload or a collective delivers it on; NULL = the legacy default stream), not on the plan's
- * stream.  Nothing changes for the caller on the plan's stream: W_dev and xhat_dev are written after everything the plan's
- * stream held at call time and are complete on it when the call returns (stream order).  What changes is inside: the
- * PREPARATION of the transform -- forward FFT, block spectra, band-passed signal (pycwt/wavelet.py:91 and the per-block
- * equivalents), which depend on the signal only and write plan scratch only -- no longer queues behind the plan's stream.  In a
- * sequence of transforms (the Monte-Carlo loop of wavelet.py:609-630, a rank of the sharded transform fed by a broadcast) it
- * runs beside the rows of the previous call instead of after them, on an otherwise idle chip.  Applies to calls whose rows are
- * all of the forms P / O / A (cwt_plan_row_classes) at nfft >= 2^18; other calls ignore the setting.  x_dev must stay
- * untouched until the call's work is complete on the plan's stream, as always.  enable = 0: back to the plan's stream. */
-int cwt_plan_set_input_stream(cwt_plan* plan, void* hip_stream, int enable);
-/* Number of cwt_transform calls that took that schedule so far (diagnostic). */
-int cwt_plan_chained_calls(cwt_plan* plan, int64_t* calls);
 
 /* ---- device memory helpers (so a NumPy-only host needs no other runtime) */
 int cwt_malloc(int device, void** ptr_dev, size_t bytes);

@@ -82,8 +82,6 @@ SYMBOLS = [
     ("cwt_plan_set_auto_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_spectrum_range", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("cwt_plan_auto_tolerance", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
-    ("cwt_plan_set_input_stream", C.c_int, [_P, _P, C.c_int]),
-    ("cwt_plan_chained_calls", C.c_int, [_P, C.POINTER(C.c_int64)]),
 ]
 
 
@@ -295,18 +293,6 @@ class Plan:
         v = C.c_double(0)
         self.lib.check(self.lib.cwt_plan_auto_tolerance(self.h, _P(xhat_dev), float(target), C.byref(v)))
         return v.value
-
-    @_locked
-    def set_input_stream(self, stream_handle, enable=True):
-        """The signals of the following transforms become ready on this stream instead of the plan's
-        (cwt_plan_set_input_stream): their preparation then runs beside the rows of the previous transform."""
-        self.lib.check(self.lib.cwt_plan_set_input_stream(self.h, _P(stream_handle or 0), int(bool(enable))))
-
-    @_locked
-    def chained_calls(self) -> int:
-        n = C.c_int64(0)
-        self.lib.check(self.lib.cwt_plan_chained_calls(self.h, C.byref(n)))
-        return n.value
 
     @_locked
     def tolerance(self) -> float:

@@ -205,9 +205,6 @@ struct cwt_plan {
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
-  int ols_fwd_split = 0;   // (transient) the two tile sizes' block spectra went to two streams
-  int ols_order = 0;       // option: 1 = the default-tile rows before the half-size-tile rows
-  int ols_split = 1;       // option: block spectra of the two tile sizes side by side on two streams (cwt_transform, ols_early)
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
@@ -324,21 +321,6 @@ struct cwt_plan {
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
   hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
-
-  // ---- signal on a stream of its own (cwt_plan_set_input_stream) -----------------------------------------------------------
-  // The preparation of a transform (forward FFT, block spectra, band-passed signal) depends on the signal only.  When the
-  // caller says on which stream the signal becomes ready, that part no longer has to queue behind what the plan's stream
-  // holds -- in a sequence of transforms: behind the ROWS of the previous call -- and runs beside them; the rows themselves
-  // (everything that writes W, and the spectrum handed back) keep waiting for the plan's stream.  One set of scratch: each
-  // preparation kernel follows the previous call's readers of its output on the same in-order chain (see transform_chained).
-  void* in_stream = nullptr;
-  bool in_stream_set = false;
-  hipStream_t chain_a = nullptr;     // forward FFT, band-passed signal + its block spectra, the rows on it, spectrum copy
-  hipEvent_t ev_in = nullptr, ev_s = nullptr, ev_xhat = nullptr, ev_coef = nullptr, ev_adone = nullptr;
-  uint64_t chain_build = 0;          // build id of the row table the chains last ran
-  bool last_chained = false;         // the previous entry into this plan was a chained transform (its readers of the scratch sit on the chains)
-  bool ev_coef_valid = false;        // a chained call has recorded ev_coef (readers of the spectrum of the previous call)
-  uint64_t chained_calls = 0;        // transforms that took the chained schedule (diagnostic)
 
   size_t esize() const { return prec == 64 ? sizeof(double) : sizeof(float); }
 };
@@ -1533,16 +1515,13 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
                        long(p->ols_x_ld), p->rt->ols_xs_sig);
   }, st);
 }
-// st1 != nullptr: the block spectra of the default-tile rows (group 1) on that stream, beside those of the half-size tiles,
-// and `ready1` recorded behind them -- the half-size-tile rows, by far the longer launch, then wait for their own spectra only.
 template <typename T>
-int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st0, hipStream_t st1 = nullptr, hipEvent_t ready1 = nullptr) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
   int rc = CWT_OK;
   {
     for (int g = 0; g < 2 && !rc; ++g) {
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows) continue;
-      hipStream_t st = (g == 1 && st1) ? st1 : st0;
       for (int d = 0; d < 3 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
@@ -1554,7 +1533,6 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st0, 
         }
       }
     }
-    if (!rc && st1 && ready1) HIPCHECK(hipEventRecord(ready1, st1));
     return rc;
   }
 }
@@ -1574,14 +1552,12 @@ int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, hipEvent_t ready1 = nullptr) {
+int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   int rc = CWT_OK;
-  for (int gi = 0; gi < 2 && !rc; ++gi) {     // the half-size tiles first (by far the longer launch since the rows with long
+  for (int g = 0; g < 2 && !rc; ++g) {        // the half-size tiles first (by far the longer launch since the rows with long
                                               // halos went to the polynomial form), then the default tile's rows
-    const int g = p->ols_order ? 1 - gi : gi; // (option ols_order = 1: the few default-tile rows first)
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows) continue;
-    if (g == 1 && ready1) HIPCHECK(hipStreamWaitEvent(st, ready1, 0));     // their block spectra came on another stream
     switch (G.logp) {
       case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
       case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
@@ -1593,9 +1569,8 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
 
 // Rows clipped at Nyquist (k_aols_*): band-passed complex signal x_M = IFFT_N(xhat mask) through the two-pass kernels
 // (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
-// part: 3 = preparation + rows (default), 1 = preparation only (band-passed signal, its block spectra), 2 = rows only
 template <typename T, int LOGP>
-int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int part = 3) {
+int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
@@ -1618,19 +1593,19 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   for (int b0 = 0; b0 < nb; b0 += chunk) {
     const int cnt = std::min(chunk, nb - b0);
     bool ok = true;
-    if (part & 1) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    rc = timed_launch(p, KC_AOLS_PRE, [&] {
       ok = try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rt->rows_dev + rt->aux_first + b0, cnt, one, 0L, 0L, Z, st);
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-    if (!rc && (part & 1)) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
       ok = try_pass_b_ct<T, false>(p, logK, nullptr, cnt, xm, p->N, p->N, Z, st);
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-    if (!rc && (part & 1)) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
       hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st, xm,
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
-    if (!rc && (part & 2)) rc = timed_launch(p, KC_AOLS, [&] {
+    if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
       hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st,
                          static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
                          static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
@@ -1641,9 +1616,9 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   return CWT_OK;
 }
 template <typename T>
-int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int part = 3) {
+int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
   switch (p->rt->aols_logp) {
-    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, part);
+    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st);
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
 }
@@ -1800,7 +1775,7 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     if (rc) return rc;
   }
   if (ols_early) {                     // block spectra already queued on side stream 1 by cwt_transform
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1], p->ols_fwd_split ? p->ev_b[0] : nullptr);
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, p->side[1]);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
@@ -2056,7 +2031,6 @@ int cwt_plan_destroy(cwt_plan* p) {
     if (p->ev_a[i]) (void)hipEventDestroy(p->ev_a[i]);
     if (p->ev_b[i]) (void)hipEventDestroy(p->ev_b[i]);
   }
-  for (hipEvent_t e : {p->ev_in, p->ev_s, p->ev_xhat, p->ev_coef, p->ev_adone}) if (e) (void)hipEventDestroy(e);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
@@ -2139,8 +2113,6 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
-  else if (k == "ols_split") p->ols_split = value != 0;
-  else if (k == "ols_order") p->ols_order = value != 0;
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "tolerance_neglog10") {   // integer alias of cwt_plan_set_tolerance for option sweeps: 10^-value; 0 = default
@@ -2171,7 +2143,6 @@ int cwt_spectrum_range(cwt_plan* p, const void* xhat_dev, int64_t n, double* max
   if (!p || !xhat_dev || !max_abs || !rms_abs || !floor_abs) return fail(CWT_EINVAL, "NULL argument");
   if (n < 1) return fail(CWT_EINVAL, "n must be >= 1");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   constexpr int kOut = SPECTRUM_SLOTS, kGroupsMax = 512;
   if (!p->range_dev && hipMalloc(reinterpret_cast<void**>(&p->range_dev), size_t(kGroupsMax + 1) * kOut * sizeof(double)) != hipSuccess)
     return fail(CWT_ENOMEM, "device allocation failed");
@@ -2245,21 +2216,6 @@ int cwt_plan_get_tolerance(cwt_plan* p, double* rel_tol) {
   return CWT_OK;
 }
 
-int cwt_plan_set_input_stream(cwt_plan* p, void* hip_stream, int enable) {
-  if (!p) return fail(CWT_EINVAL, "plan is NULL");
-  HIPCHECK(hipSetDevice(p->device));
-  HIPCHECK(hipStreamSynchronize(p->stream));
-  p->in_stream = hip_stream;
-  p->in_stream_set = enable != 0;
-  return CWT_OK;
-}
-
-int cwt_plan_chained_calls(cwt_plan* p, int64_t* calls) {
-  if (!p || !calls) return fail(CWT_EINVAL, "NULL argument");
-  *calls = int64_t(p->chained_calls);
-  return CWT_OK;
-}
-
 int cwt_plan_sync(cwt_plan* p) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipStreamSynchronize(p->stream));
@@ -2280,7 +2236,6 @@ int cwt_free(int device, void* ptr) {
 int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
   HIPCHECK(hipStreamSynchronize(p->stream));
   return CWT_OK;
@@ -2288,7 +2243,6 @@ int cwt_memcpy_h2d(cwt_plan* p, void* dst, const void* src, size_t bytes) {
 int cwt_memcpy_d2h(cwt_plan* p, void* dst, const void* src, size_t bytes) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return copy_d2h(p, dst, src, bytes);
 }
 
@@ -2296,7 +2250,6 @@ int cwt_forward_fft(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) 
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
                        : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
 }
@@ -2433,118 +2386,6 @@ int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, 
                        : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
 }
 
-// ---- the signal on a stream of its own: three in-order chains ----------------------------------------------------------
-bool chained_applies(const cwt_plan* p) {
-  const cwt_plan::RowTable* rt = p->rt;
-  return p->in_stream_set && !p->profile && !p->graph && !rt->n_small && !rt->n_narrow && !rt->n_wide &&
-         rt->poly_chunks.size() <= 1 && rt->ols_nbatch == 1 && rt->aols_nbatch == 1 && (rt->n_poly + rt->n_ols + rt->n_aols) > 0 &&
-         p->logN >= p->ols_min_logn && check_geometry(p) == CWT_OK;
-}
-
-int chained_init(cwt_plan* p) {
-  if (p->chain_a) return CWT_OK;
-  // the third side stream of the plan, created together with the other two: three consecutive streams sit on three different
-  // hardware queues (a stream created later shared its queue with side stream 1, and the two chains ran one after the other)
-  p->chain_a = p->side2;
-  for (hipEvent_t* e : {&p->ev_in, &p->ev_s, &p->ev_xhat, &p->ev_coef, &p->ev_adone})
-    HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  return CWT_OK;
-}
-
-// cwt_transform with the signal ready on p->in_stream and every row of the forms P / O / A.  Contract on the plan's stream S
-// as always: everything that writes W_dev / xhat_dev waits for S at call time, S waits for all of it at the end.  What does
-// NOT wait for S is the preparation, which writes plan scratch only:
-//   chain A (own stream)  wait(in, spectrum readers of the previous call) -> forward FFT -> band-passed signal, its block spectra
-//                         -> wait(S) -> [copy of the spectrum to xhat_dev] -> rows on the band-passed signal
-//   chain O (side 1)      wait(in) -> block spectra -> wait(S) -> overlap-save rows
-//   chain P (side 0)      wait(spectrum) -> bands, coefficients -> wait(S) -> polynomial rows
-// In a sequence of calls S holds the join of the previous call, so the rows of call c + 1 start when ALL rows of call c are
-// done (heavy kernels never overlap: k_ols_ct beside k_poly_rows costs +35 %, EXPERIMENTS.md R5.2), while FFT, block
-// spectra and band-passed signal of call c + 1 ran beside the polynomial rows of call c: a step no longer starts with ~60 us
-// of latency-bound launches on an idle chip.  ONE set of scratch (a second set pushes the coefficient planes out of the
-// Infinity Cache, R5.2): every preparation kernel sits behind the previous call's readers of its output on the same chain
-// (block spectra <- overlap-save rows; band-passed signal <- its rows; bands / planes <- polynomial rows), except the spectrum,
-// whose readers on chain P are awaited through ev_coef.
-template <typename T>
-int transform_chained(cwt_plan* p, const void* x_dev, int64_t n0, const Mother& mo, void* xhat_user, void* W_dev,
-                      int64_t ldw, int64_t ncols) {
-  int rc = chained_init(p);
-  if (rc) return rc;
-  const cwt_plan::RowTable* rt = p->rt;
-  cplx<T>* W = static_cast<cplx<T>*>(W_dev);
-  hipStream_t cA = p->chain_a, cO = p->side[1], cP = p->side[0], S = p->stream;
-  const bool need_xhat = rt->n_poly || rt->n_aols || xhat_user;
-  if (rt->n_ols) rc = grow(&p->xs, &p->xs_bytes, size_t(rt->ols_xs_elems) * sizeof(cplx<T>), S);
-  if (!rc && need_xhat) rc = grow(&p->hxhat, &p->hxhat_bytes, size_t(p->N) * sizeof(cplx<T>), S);
-  if (rc) return rc;
-  const void* xhat = p->hxhat;
-  HIPCHECK(hipEventRecord(p->ev_in, static_cast<hipStream_t>(p->in_stream)));
-  HIPCHECK(hipEventRecord(p->ev_s, S));
-  if (!p->last_chained || p->chain_build != rt->build_id) {
-    // the previous entry into the plan was something else: its kernels (joined into S) may still read the scratch, and they do
-    // not sit on these chains -- or the row table was (re)built by this call, its upload and filter tables sit on S: this
-    // once the preparation waits for S too
-    p->chain_build = rt->build_id;
-    for (hipStream_t st : {cA, cO, cP}) HIPCHECK(hipStreamWaitEvent(st, p->ev_s, 0));
-    p->ev_coef_valid = false;
-  }
-  // chain O
-  if (rt->n_ols) {
-    HIPCHECK(hipStreamWaitEvent(cO, p->ev_in, 0));
-    rc = launch_ols_fwd<T>(p, x_dev, n0, cO);
-    if (rc) return rc;
-    HIPCHECK(hipStreamWaitEvent(cO, p->ev_s, 0));
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, cO);
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_ols, cO));
-  }
-  // chain A
-  HIPCHECK(hipStreamWaitEvent(cA, p->ev_in, 0));
-  if (need_xhat) {
-    if (p->ev_coef_valid) HIPCHECK(hipStreamWaitEvent(cA, p->ev_coef, 0));    // bands of the previous call have read the spectrum
-    {
-      StreamGuard guard(p);
-      p->stream = cA;
-      rc = fft_rows_impl<T, IN_REAL>(p, x_dev, 0, 1, n0, p->hxhat);
-    }
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_xhat, cA));
-  }
-  if (rt->n_aols) {
-    rc = launch_aols<T>(p, xhat, W, ldw, ncols, cA, 1);
-    if (rc) return rc;
-  }
-  HIPCHECK(hipStreamWaitEvent(cA, p->ev_s, 0));
-  if (xhat_user)
-    HIPCHECK(hipMemcpyAsync(xhat_user, p->hxhat, size_t(p->N) * sizeof(cplx<T>), hipMemcpyDeviceToDevice, cA));
-  if (rt->n_aols) {
-    rc = launch_aols<T>(p, xhat, W, ldw, ncols, cA, 2);
-    if (rc) return rc;
-  }
-  HIPCHECK(hipEventRecord(p->ev_adone, cA));
-  // chain P
-  if (rt->n_poly) {
-    HIPCHECK(hipStreamWaitEvent(cP, p->ev_xhat, 0));
-    rc = launch_poly_coef<T>(p, static_cast<const cplx<T>*>(xhat), mo, 0, cP, nullptr);
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_coef, cP));
-    p->ev_coef_valid = true;
-    HIPCHECK(hipStreamWaitEvent(cP, p->ev_s, 0));
-    rc = launch_poly_rows<T>(p, 0, W, ldw, ncols, cP);
-    if (rc) return rc;
-    HIPCHECK(hipEventRecord(p->ev_a[0], cP));
-  } else {
-    p->ev_coef_valid = false;
-  }
-  // join
-  HIPCHECK(hipStreamWaitEvent(S, p->ev_adone, 0));
-  if (rt->n_ols) HIPCHECK(hipStreamWaitEvent(S, p->ev_ols, 0));
-  if (rt->n_poly) HIPCHECK(hipStreamWaitEvent(S, p->ev_a[0], 0));
-  ++p->chained_calls;
-  p->last_chained = true;
-  return CWT_OK;
-}
-
 // The overlap-save rows need the signal only: cwt_transform queues them on side stream 1 BEFORE the forward FFT, so
 // that they run beside it and beside the two-pass chain; rows_impl then skips them and joins the stream at its end.
 template <typename T>
@@ -2553,10 +2394,7 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
-  p->ols_fwd_split = p->ols_split && p->rt->ols_grp[0].nrows && p->rt->ols_grp[1].nrows;
-  if (p->ols_fwd_split) HIPCHECK(hipStreamWaitEvent(p->side2, p->ev_fork, 0));
-  rc = p->ols_fwd_split ? launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->side2, p->ev_b[0])
-                        : launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
+  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
   if (rc) return rc;                                    // polynomial rows)
   (void)W_dev; (void)ldw; (void)ncols;
   p->ols_launched = 1;
@@ -2569,7 +2407,6 @@ int cwt_transform_rows(cwt_plan* p, const void* xhat_dev, int mother, double par
                        const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
   if (!p || !xhat_dev || !scales || !W_dev) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return transform_rows_common(p, xhat_dev, nullptr, 0, mother, param, dt, scales, nrows, W_dev, ldw, ncols);
 }
 
@@ -2580,20 +2417,6 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   HIPCHECK(hipSetDevice(p->device));
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
   if (rc) return rc;
-  if (chained_applies(p)) {
-    const Mother cmo = mother_of(mother, param);
-    rc = p->prec == 64 ? transform_chained<double>(p, x_dev, n0, cmo, xhat_dev, W_dev, ldw, ncols)
-                       : transform_chained<float>(p, x_dev, n0, cmo, xhat_dev, W_dev, ldw, ncols);
-    if (rc) {                                                // drain the chains: nothing may still read the row table or scratch
-      const std::string msg = g_err;
-      for (hipStream_t st : {p->chain_a, p->side[0], p->side[1]}) if (st) (void)hipStreamSynchronize(st);
-      (void)hipGetLastError();
-      g_err = msg;
-      p->last_chained = false;
-    }
-    return rc;
-  }
-  p->last_chained = false;
   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
   const bool only_ols = !xhat_dev && p->rt->n_ols == nrows;      // every row is an overlap-save row on the real signal
   if (!xhat_dev && !only_ols) {
@@ -2603,7 +2426,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   }
   const Mother mo = mother_of(mother, param);
   auto enqueue = [&]() -> int {
-    p->ols_launched = 0; p->ols_fwd_split = 0;
+    p->ols_launched = 0;
     int r = CWT_OK;
     if (only_ols)
       return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
@@ -2617,7 +2440,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
                       : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
     if (!r) r = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                               : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
-    p->ols_launched = 0; p->ols_fwd_split = 0;
+    p->ols_launched = 0;
     return r;
   };
   if (!p->graph || p->profile) return enqueue();
@@ -2675,7 +2498,6 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   const int total = nbatch * nrows;
   const std::vector<double> key = call_key(2, {double(mother), param, dt, double(nbatch), double(xhat_ld), double(nrows)},
                                            {{scales, nrows}});
@@ -2715,7 +2537,6 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   const int total = nbatch * nrows;
   const std::vector<double> key = call_key(3, {double(mother), param, dt, double(nbatch), double(nrows), double(ncols)},
                                            {{scales, nrows}});
@@ -2747,7 +2568,7 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
   int rc = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev)
                          : fft_rows_impl<float, IN_REAL>(p, x_dev, x_ld, nbatch, n0, xhat_dev);
   if (rc) return rc;
-  p->ols_launched = 0; p->ols_fwd_split = 0;
+  p->ols_launched = 0;
   p->ols_x_ld = x_ld;
   rc = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0)
                      : rows_impl<float>(p, xhat_dev, mo, total, W_dev, ldw, ncols, x_dev, n0);
@@ -2761,7 +2582,6 @@ int cwt_transform_rows_table(cwt_plan* p, const void* xhat_dev, const void* tabl
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   select_table(p, {});                                   // explicit filter banks are not cached
   std::vector<double> one(nrows, 1.0), zero(nrows, 0.0);
   int rc = build_row_table(p, MOTHER_TABLE, 0.0, one.data(), one.data(), zero.data(), 0, nrows, k_lo, nband);
@@ -2780,7 +2600,6 @@ int cwt_fft_rows(cwt_plan* p, const void* in_dev, int in_complex, int nrows, int
   if (nrows < 1) return fail(CWT_EINVAL, "nrows must be >= 1");
   if (ncols_in < 1 || ncols_in > p->N || in_ld < ncols_in) return fail(CWT_EINVAL, "need 1 <= ncols_in <= nfft and in_ld >= ncols_in");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   if (p->prec == 64)
     return in_complex ? fft_rows_impl<double, IN_CPLX>(p, in_dev, in_ld, nrows, ncols_in, spec_dev)
                       : fft_rows_impl<double, IN_REAL>(p, in_dev, in_ld, nrows, ncols_in, spec_dev);
@@ -2796,7 +2615,6 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (spec_ld != 0 && spec_ld < p->N) return fail(CWT_EINVAL, "spec_ld must be 0 (shared) or >= nfft");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   const std::vector<double> key = call_key(1, {double(mother), param, double(spec_ld), double(nrows)},
                                            {{a, nrows}, {amp_re, nrows}, {amp_im, nrows}});
   if (!select_table(p, key)) {
@@ -2882,7 +2700,6 @@ int cwt_wct_products(cwt_plan* p, const void* W1_dev, const void* W2_dev, const 
   if (!p || !W1_dev || !W2_dev || !scales || !P_dev || !C_dev || !angle_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || nrows > p->max_rows || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? wct_products_impl<double>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev)
                        : wct_products_impl<float>(p, W1_dev, W2_dev, scales, nrows, ld, ncols, P_dev, C_dev, angle_dev);
 }
@@ -2892,7 +2709,6 @@ int cwt_cross_spectrum(cwt_plan* p, const void* W1_dev, const void* W2_dev, int 
   if (!p || !W1_dev || !W2_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || nrows > 65535 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   const dim3 grid(unsigned((ncols + 255) / 256), unsigned(nrows));
   return timed_launch(p, KC_ELEMENTWISE, [&] {
     if (p->prec == 64)
@@ -2910,7 +2726,6 @@ int cwt_boxcar_scales(cwt_plan* p, const void* in_dev, int nrows, int64_t ld, in
   if (nrows < 1 || ncols < 1 || ld < ncols || nwin < 1 || nwin > p->max_rows) return fail(CWT_EINVAL, "bad shape");
   if (in_dev == out_dev) return fail(CWT_EINVAL, "boxcar cannot run in place");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? boxcar_impl<double>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev)
                        : boxcar_impl<float>(p, in_dev, nrows, ld, ncols, win, nwin, out_dev);
 }
@@ -2920,7 +2735,6 @@ int cwt_wct_coherence(cwt_plan* p, const void* S_dev, const void* S12_dev, int n
   if (!p || !S_dev || !S12_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || ncols < 1 || ld < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? coherence_impl<double>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev)
                        : coherence_impl<float>(p, S_dev, S12_dev, nrows, ld, ncols, out_dev);
 }
@@ -2948,7 +2762,6 @@ int cwt_reduce_scales(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncols
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "need ncols >= 1 and ldw >= ncols");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   if (p->prec == 64)
     return power ? reduce_scales_impl<double, true>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev)
                  : reduce_scales_impl<double, false>(p, W_dev, ldw, ncols, nrows, weights, coeff, out_dev);
@@ -2972,7 +2785,6 @@ int cwt_time_mean_power(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t nco
   if (!p || !W_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
   if (nrows < 1 || ncols < 1 || ldw < ncols) return fail(CWT_EINVAL, "bad shape");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   if (p->prec == 64)
     return timed_launch(p, KC_ICWT, [&] {
       hipLaunchKernelGGL((k_time_mean<double>), dim3(nrows), dim3(256), 256 * sizeof(double), p->stream,
@@ -2990,7 +2802,6 @@ int cwt_coherence_histogram(cwt_plan* p, const void* r2_dev, int64_t ld, int nro
   if (nrows < 1 || ld < 1 || nbins < 1 || nbins > 16384 || max_span < 0) return fail(CWT_EINVAL, "bad shape");
   if (max_span == 0) return CWT_OK;
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   static_assert(sizeof(long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "LP64 expected");
   const unsigned gx = unsigned(std::min<int64_t>(512, (max_span + 4095) / 4096));   // >= 16 columns per thread
   const size_t lds = size_t(nbins) * sizeof(unsigned);
@@ -3117,7 +2928,6 @@ int transform_rows_n_impl(cwt_plan* p, const void* xhat_dev, int64_t n0, int mot
 int cwt_forward_fft_n(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? forward_fft_n_impl<double>(p, x_dev, n0, xhat_dev) : forward_fft_n_impl<float>(p, x_dev, n0, xhat_dev);
 }
 
@@ -3129,7 +2939,6 @@ int cwt_transform_rows_n(cwt_plan* p, const void* xhat_dev, int64_t n0, int moth
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   if (mother < MOTHER_MORLET || mother > MOTHER_DOG) return fail(CWT_EINVAL, "unknown mother id");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   return p->prec == 64 ? transform_rows_n_impl<double>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw)
                        : transform_rows_n_impl<float>(p, xhat_dev, n0, mother, param, dt, scales, nrows, W_dev, ldw);
 }
@@ -3179,7 +2988,6 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (!p || !x_host || !scales) return fail(CWT_EINVAL, "NULL argument");
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   const size_t es = p->esize();
   // A transform that fits one workgroup per row (the reference's canonical 504-point call: 4 KB in, 0.8 MB out) is all
   // latency, and copy operations are the larger part of it.  Here it has none: the forward FFT reads the signal from the
@@ -3318,7 +3126,6 @@ int cwt_plan_classify(cwt_plan* p, int mother, double param, double dt, const do
                       int with_signal, int* codes) {
   if (!p || !scales || !codes) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));
-  p->last_chained = false;   // (the next chained transform must not start its preparation before this call's work)
   int rc = prepare_rows_table(p, with_signal != 0, mother, param, dt, scales, nrows, ncols, ncols);
   if (rc) return rc;
   int n = 0;

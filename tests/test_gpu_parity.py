@@ -1032,69 +1032,3 @@ def test_polynomial_rows_in_chunks_at_full_size(hip_library):
             b.free()
         plan.close()
     assert np.array_equal(out[96], out[0]) and np.array_equal(out[24], out[0])
-
-
-@pytest.mark.parametrize("name,prec", [("morlet", 64), ("dog", 32), ("paul", 32)])
-def test_chained_calls_keep_every_bit_of_the_ordinary_calls(hip_library, name, prec):
-    """cwt_plan_set_input_stream: the signal becomes ready on a stream of its own, so the preparation of a transform (forward
-    FFT, block spectra, band-passed signal) runs beside the rows of the previous transform instead of behind them; ONE set of
-    scratch.  Seven different signals uploaded on the feed stream and transformed back to back, each into its own W and
-    spectrum buffer, twice over: every bit equals the ordinary schedule's.  A preparation kernel that overwrote scratch its
-    predecessor's rows still read (block spectra, band-passed signal, spectrum, planes) would show as a wrong block of a row."""
-    import torch
-    N = 1 << 20
-    kind, param = MOTHERS[name]
-    m = orc.Mother(kind, param)
-    s0 = 2 / m.flambda()
-    sj = (s0 * 2 ** (np.arange(256) * np.log2(N / s0) / 255))[:192:3]     # 64 rows: overlap-save, band-passed, polynomial
-    tdt, cdt = (torch.float64, torch.complex128) if prec == 64 else (torch.float32, torch.complex64)
-    tol = 1e-9 if prec == 64 else 3e-5
-    dev = torch.device("cuda", 0)
-    feed = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream()
-    K = 7
-    host = [torch.from_numpy(np.random.default_rng(300 + i).standard_normal(N) * (1.0 + i)).to(tdt).pin_memory() for i in range(K)]
-    plan = _hip.Plan(N, prec, max_rows=64, options={"tolerance": tol})
-    plan.set_stream(main.cuda_stream)
-    plan.set_input_stream(feed.cuda_stream, True)
-    xd = [torch.empty(N, dtype=tdt, device=dev) for _ in range(K)]
-    xh = [torch.zeros(N, dtype=cdt, device=dev) for _ in range(K)]
-    W = [torch.zeros((len(sj), N), dtype=cdt, device=dev) for _ in range(K)]
-    torch.cuda.synchronize()
-    for rep in range(2):
-        for i in range(K):
-            if rep == 0:
-                with torch.cuda.stream(feed):
-                    xd[i].copy_(host[i], non_blocking=True)          # the signal becomes ready on `feed`, not on `main`
-            plan.transform(xd[i].data_ptr(), N, kind, float(param), 1.0, sj, xh[i].data_ptr(), W[i].data_ptr(), N, N)
-    torch.cuda.synchronize()
-    classes = plan.row_classes()
-    if all(c.split("/")[0] in ("poly", "ols", "aols") for c in classes):
-        assert plan.chained_calls() == 2 * K
-    else:                                                            # (fp32 Paul keeps two two-pass rows: the setting is ignored)
-        assert plan.chained_calls() == 0
-    ref = _hip.Plan(N, prec, max_rows=64, options={"tolerance": tol})
-    ref.set_stream(main.cuda_stream)
-    rh, rW = torch.empty_like(xh[0]), torch.empty_like(W[0])
-    for i in range(K):
-        ref.transform(xd[i].data_ptr(), N, kind, float(param), 1.0, sj, rh.data_ptr(), rW.data_ptr(), N, N)
-        torch.cuda.synchronize()
-        bad = torch.nonzero((W[i] != rW).any(dim=1)).flatten().tolist()
-        assert not bad, (i, bad[:8], [classes[j] for j in bad[:8]])
-        assert torch.equal(xh[i], rh), i
-    assert ref.chained_calls() == 0
-    idx = [0, 21, 42, 63]
-    with np.errstate(all="ignore"):
-        want = orc.cwt_rows(host[K - 1].numpy().astype(np.float64), 1.0, sj[idx], m, intended=True)
-    per_row, _ = row_errors(W[K - 1][idx].cpu().numpy(), want)
-    assert per_row.max() < (1e-8 if prec == 64 else 1e-4)
-    # the same W for every call + another entry point of the plan in between
-    out = torch.empty(N, dtype=tdt, device=dev)
-    for i in range(K):
-        plan.transform(xd[i].data_ptr(), N, kind, float(param), 1.0, sj, xh[0].data_ptr(), W[0].data_ptr(), N, N)
-        if i == 3:
-            plan.icwt_reduce(W[0].data_ptr(), N, N, sj, 1.0, out.data_ptr())
-    torch.cuda.synchronize()
-    assert torch.equal(W[0], rW) and torch.equal(xh[0], rh)
-    plan.close()
-    ref.close()
