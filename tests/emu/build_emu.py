@@ -10,19 +10,31 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_build", "libcwt_emu.so")
-SRCS = [os.path.join(ROOT, "pycwt_amd", "csrc", "cwt_abi.hip"), os.path.join(HERE, "hipemu.cpp")]
-DEPS = SRCS + [os.path.join(ROOT, "pycwt_amd", "csrc", f) for f in ("fft_engine.hpp", "cwt_kernels.hpp")] + [
+CSRC = os.path.join(ROOT, "pycwt_amd", "csrc")
+UNITS = ["plan_host.cpp", "launch_f64.hip", "launch_f32.hip", "abi.hip"]       # the product's translation units, unmodified
+SRCS = [os.path.join(CSRC, u) for u in UNITS] + [os.path.join(HERE, "hipemu.cpp")]
+DEPS = SRCS + [os.path.join(CSRC, f) for f in ("plan.hpp", "cwt_types.hpp", "launch_impl.hpp", "fft_engine.hpp", "cwt_kernels.hpp",
+                                               "cwt_kernels_rows.hpp", "cwt_kernels_callers.hpp")] + [
     os.path.join(ROOT, "include", "cwt_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
 
 
 def build(force=False):
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-DCWT_BACKEND_NAME=\"cpu-emulation\"",
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "pycwt_amd", "csrc"),
-           "-x", "c++", SRCS[0], SRCS[1], "-o", OUT]
-    subprocess.run(cmd, check=True)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-DCWT_BACKEND_NAME=\"cpu-emulation\"",
+             "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".emu.o")
+        subprocess.run(["g++"] + flags + ["-x", "c++", "-c", src, "-o", obj], check=True)
+        return obj
+    with ThreadPoolExecutor(max_workers=len(SRCS)) as pool:
+        objs = list(pool.map(compile_one, SRCS))
+    subprocess.run(["g++", "-shared", "-pthread"] + objs + ["-o", OUT + ".tmp"], check=True)
+    os.replace(OUT + ".tmp", OUT)
     return OUT
 
 

@@ -6,10 +6,11 @@ import sys
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", "include", "-I",
-       "pycwt_amd/csrc", "pycwt_amd/csrc/cwt_abi.hip", "-o", "/tmp/_res.so",
-       "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
-out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
+out = ""
+for unit in ("launch_f64.hip", "launch_f32.hip", "abi.hip"):          # the translation units that hold device code
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", "include", "-I", "pycwt_amd/csrc", "-c",
+           "pycwt_amd/csrc/" + unit, "-o", "/tmp/_res.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
+    out += subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():

@@ -15,12 +15,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 want = sys.argv[1:] or ["k_narrow_ct_all", "k_narrow_ct_many", "k_narrow_ct_big", "k_ols_ct", "k_ols_fwd_r", "k_pass_a_ct_rows<",
                         "k_pass_b_ct"]
+lines = []
 with tempfile.TemporaryDirectory() as tmp:
-    asm = os.path.join(tmp, "cwt.s")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
-                    os.path.join(ROOT, "pycwt_amd", "csrc"), "--cuda-device-only", "-S",
-                    os.path.join(ROOT, "pycwt_amd", "csrc", "cwt_abi.hip"), "-o", asm], check=True, capture_output=True)
-    lines = open(asm).read().splitlines()
+    for unit in ("launch_f64.hip", "launch_f32.hip"):
+        asm = os.path.join(tmp, unit + ".s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
+                        os.path.join(ROOT, "pycwt_amd", "csrc"), "--cuda-device-only", "-S",
+                        os.path.join(ROOT, "pycwt_amd", "csrc", unit), "-o", asm], check=True, capture_output=True)
+        lines += open(asm).read().splitlines()
 starts = [(i, m.group(1)) for i, l in enumerate(lines) if (m := re.match(r"^(_Z\w+):", l))]
 for idx, (i, sym) in enumerate(starts):
     name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
