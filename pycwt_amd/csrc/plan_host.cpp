@@ -196,7 +196,24 @@ double profile_peak_f(int mother, double p) {
 // tail carries less than eps of the L1 mass of |psi| (the bound on the relative error of any output sample):
 //   Morlet, DOG m: |psi(eta)| = |He_m(eta)| exp(-eta^2/2) (m = 0 for Morlet) -- numerical quadrature;
 //   Paul m:        |psi(eta)| = (1 + eta^2)^(-(m+1)/2)   -- tail <= c^-m / m, total sqrt(pi) Gamma(m/2) / (2 Gamma((m+1)/2)).
+double time_halo_factor_compute(int mother, double param, double eps);
 double time_halo_factor(int mother, double param, double eps) {
+  // depends on the mother and the accuracy target only, never on the scales: the last few answers are kept (the quadrature
+  // below is 0.1 - 0.4 ms of every row-table build otherwise)
+  struct Entry { int mother; double param, eps, value; };
+  static std::mutex mu;
+  static std::vector<Entry> memo;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : memo) if (e.mother == mother && e.param == param && e.eps == eps) return e.value;
+  }
+  const double v = time_halo_factor_compute(mother, param, eps);
+  std::lock_guard<std::mutex> lk(mu);
+  if (memo.size() >= 32) memo.erase(memo.begin());
+  memo.push_back({mother, param, eps, v});
+  return v;
+}
+double time_halo_factor_compute(int mother, double param, double eps) {
   if (mother == MOTHER_PAUL) {
     const double m = param;
     const double total = 0.5 * std::sqrt(3.14159265358979323846) * std::tgamma(0.5 * m) / std::tgamma(0.5 * (m + 1.0));
@@ -229,22 +246,33 @@ double time_halo_factor(int mother, double param, double eps) {
 // in-place radix-2 inverse DFT (e^{+2 pi i k n / n}, unnormalised) of a power-of-two length; host helper of aols_halo
 void host_ifft(std::vector<std::complex<double>>& v) {
   const size_t n = v.size();
+  // twiddles e^{2 pi i k / n}, k < n/2, of the last length used (the halo search calls this with one length per table);
+  // plain real arithmetic: std::complex's operator* checks for NaN on every product
+  static thread_local std::vector<double> twr, twi;
+  if (twr.size() != n / 2) {
+    twr.resize(n / 2); twi.resize(n / 2);
+    for (size_t k = 0; k < n / 2; ++k) {
+      const double ang = 6.283185307179586476925 * double(k) / double(n);
+      twr[k] = std::cos(ang); twi[k] = std::sin(ang);
+    }
+  }
   for (size_t i = 1, j = 0; i < n; ++i) {
     size_t bit = n >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
     j ^= bit;
     if (i < j) std::swap(v[i], v[j]);
   }
+  double* d = reinterpret_cast<double*>(v.data());          // (re, im) pairs
   for (size_t len = 2; len <= n; len <<= 1) {
-    const double ang = 6.283185307179586476925 / double(len);
-    const std::complex<double> wl(std::cos(ang), std::sin(ang));
+    const size_t half = len / 2, stride = n / len;
     for (size_t i = 0; i < n; i += len) {
-      std::complex<double> w(1.0, 0.0);
-      for (size_t k = 0; k < len / 2; ++k) {
-        const std::complex<double> a = v[i + k], b = v[i + k + len / 2] * w;
-        v[i + k] = a + b;
-        v[i + k + len / 2] = a - b;
-        w *= wl;
+      for (size_t k = 0; k < half; ++k) {
+        const double wr = twr[k * stride], wi = twi[k * stride];
+        double* a = d + 2 * (i + k);
+        double* b = d + 2 * (i + k + half);
+        const double br = b[0] * wr - b[1] * wi, bi = b[0] * wi + b[1] * wr;
+        b[0] = a[0] - br; b[1] = a[1] - bi;
+        a[0] += br; a[1] += bi;
       }
     }
   }
@@ -273,7 +301,17 @@ double host_aols_window(const AolsGeom& g, double f) {
 // eps of its L1 mass -- the bound on the relative error of an output sample, as for the overlap-save rows on the real
 // signal -- or 0 if there is none or if the row does not qualify (see below).  e is evaluated numerically on a 4 hmax-point grid (its wrap-around beyond 2 hmax
 // samples is far below eps for every row that passes).
-int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps, int hmax) {
+// The window u on that grid (the same for every row of a table: computed once, two erfc per point otherwise)
+std::vector<double> aols_window_grid(const AolsGeom& g, int hmax) {
+  const int n = 4 * hmax, k0 = int(std::ceil(g.f_s * n));
+  std::vector<double> w(static_cast<size_t>(n));
+  for (int q = 0; q < n; ++q) {
+    const int kappa = k0 + (((q - k0) % n) + n) % n;
+    w[size_t(q)] = host_aols_window(g, double(kappa) / double(n));
+  }
+  return w;
+}
+int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps, int hmax, const std::vector<double>& window) {
   const int n = 4 * hmax;
   std::vector<std::complex<double>> e(size_t(n), std::complex<double>(0.0, 0.0));
   const int k0 = int(std::ceil(g.f_s * n));
@@ -281,7 +319,8 @@ int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps
   for (int q = 0; q < n; ++q) {
     const int kappa = k0 + (((q - k0) % n) + n) % n;
     const double f = double(kappa) / double(n);
-    const double v = host_profile(mother, param, aN * f) * host_aols_window(g, f);
+    const double u = window[size_t(q)];
+    const double v = u != 0.0 ? host_profile(mother, param, aN * f) * u : 0.0;
     e[size_t(q)] = v;
     (f <= 0.5 ? in_band : beyond) = std::max(f <= 0.5 ? in_band : beyond, std::fabs(v));
   }
@@ -323,21 +362,31 @@ double erfc_arg(double tail) {
 //   F(kappa) / F_max * |theta_kappa|^(D+1) / (D+1)!  <=  eps   on the band,  theta = pi kappa / K'
 // (F_max = the filter's largest value on the row's bins, log_best its log relative to the profile's peak) -- the truncated
 // Taylor terms are bounded like the bins beyond the support threshold.  The band is sampled at <= 257 points.
-int poly_degree_for(int mother, double param, double a, int kc, int k_lo, int nband, int logk, double log_best, double eps) {
-  const int npts = std::min(nband, 257);
-  const double tscale = 3.14159265358979323846 / double(1 << logk);
-  std::vector<double> term(static_cast<size_t>(npts), 0.0), th(static_cast<size_t>(npts), 0.0);
+constexpr int POLY_SAMPLES = 257;
+struct PolyBandSamples {     // the row's filter relative to its largest value on the bins, and |kappa| (+ 1), at <= 257 bins of the band
+  int npts = 0;
+  double g[POLY_SAMPLES], kap[POLY_SAMPLES];
+};
+void poly_band_samples(int mother, double param, double a, int kc, int k_lo, int nband, double log_best, PolyBandSamples* out) {
+  const int npts = std::min(nband, POLY_SAMPLES);
+  out->npts = npts;
   for (int i = 0; i < npts; ++i) {
     const int k = k_lo + (npts > 1 ? int((long(nband - 1) * i) / (npts - 1)) : 0);
     const double lg = profile_log_rel(mother, param, a * double(k)) - log_best;
-    term[size_t(i)] = std::isfinite(lg) ? std::exp(std::min(lg, 0.0)) : 0.0;
-    th[size_t(i)] = std::fabs(double(k - kc) + (k >= kc ? 1.0 : -1.0)) * tscale;   // + 1: the sampling skips neighbours
+    out->g[i] = std::isfinite(lg) ? std::exp(std::min(lg, 0.0)) : 0.0;
+    out->kap[i] = std::fabs(double(k - kc) + (k >= kc ? 1.0 : -1.0));         // + 1: the sampling skips neighbours
   }
+}
+int poly_degree_for(const PolyBandSamples& b, int logk, double eps) {
+  const double tscale = 3.14159265358979323846 / double(1 << logk);
+  double term[POLY_SAMPLES], th[POLY_SAMPLES];
+  for (int i = 0; i < b.npts; ++i) { term[i] = b.g[i]; th[i] = b.kap[i] * tscale; }
   for (int d = 0; d <= POLY_MAX_DEGREE + 1; ++d) {
     double worst = 0;
-    for (int i = 0; i < npts; ++i) {
-      term[size_t(i)] *= th[size_t(i)] / double(d + 1);
-      worst = std::max(worst, term[size_t(i)]);
+    const double inv = 1.0 / double(d + 1);
+    for (int i = 0; i < b.npts; ++i) {
+      term[i] *= th[i] * inv;
+      worst = std::max(worst, term[i]);
     }
     if (worst <= eps && d >= 2 && (d & 1) == 0) return d;
   }
@@ -560,8 +609,10 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       if (poly_ok && rd.nband > 0) {
         const int lk_max = std::min(p->poly_max_logk, p->logN - POLY_MIN_LOGR);
         const int kc = rd.k_lo + (rd.nband >> 1);
+        PolyBandSamples band;
+        if (std::max(8, ilog2(rd.nband)) <= lk_max) poly_band_samples(mother, param, rd.a, kc, rd.k_lo, rd.nband, row_best, &band);
         for (int lk = std::max(8, ilog2(rd.nband)); lk <= lk_max; ++lk) {
-          const int deg = poly_degree_for(mother, param, rd.a, kc, rd.k_lo, rd.nband, lk, row_best, tol.support);
+          const int deg = poly_degree_for(band, lk, tol.support);
           if (deg > POLY_MAX_DEGREE) continue;
           poly_logk = lk; poly_deg = deg;
           if (deg <= p->poly_degree) break;
@@ -635,10 +686,11 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     if (geom_ok) {
       const double eps = std::max(tol.halo, p->prec == 64 ? 2e-14 : 5e-7);
       std::vector<int> halo_of_scale(size_t(rps), -1);     // (a numeric tail search each: once per scale, not per signal)
+      const std::vector<double> window = aols_window_grid(ag, 512);
       for (size_t i = 0; i < wide_rows.size(); ++i) {
         if (!wide_clipped[i]) continue;
         int& h = halo_of_scale[size_t(wide_rows[i].out_row % rps)];
-        if (h < 0) h = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512);
+        if (h < 0) h = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512, window);
         halos[i] = h;
         if (halos[i]) { ++cnt; hmax_seen = std::max(hmax_seen, halos[i]); }
       }
