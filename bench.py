@@ -511,15 +511,43 @@ def config5_callers(logn=20, dj=0.25):
             ts.append(time.perf_counter() - t0)
             del out
         return min(ts) * 1e3, shape
+    def best_device(f, reps=3):
+        ts = []
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            out = f()
+            ts.append(time.perf_counter() - t0)
+            (out[0] if isinstance(out, tuple) else out).close()
+        return min(ts[1:]) * 1e3
+
+    def mc_draw_ms(rng_name, draws=6):
+        """ms per Monte-Carlo draw of wct_significance on the surrogate length of this grid (wavelet.py:609-630)."""
+        m = pycwt_amd.Morlet(6)
+        s0 = 2 * 1.0 / m.flambda()
+        J = int(np.round(np.log2(n * 1.0 / s0) / dj))
+        kw = dict(progress=False, cache=False, rng=rng_name)
+        np.random.seed(3)
+        pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=2, **kw)            # plans, row tables
+        t0 = time.perf_counter()
+        pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=draws, **kw)
+        return (time.perf_counter() - t0) / draws * 1e3
     try:
         x_ms, shape = best(lambda: pycwt_amd.xwt(y1, y2, 1.0, dj))
         w_ms, _ = best(lambda: pycwt_amd.wct(y1, y2, 1.0, dj, sig=False))
+        xd_ms = best_device(lambda: pycwt_amd.xwt_device(y1, y2, 1.0, dj))
+        wd_ms = best_device(lambda: pycwt_amd.wct_device(y1, y2, 1.0, dj))
+        mc_np, mc_dev = mc_draw_ms("numpy"), mc_draw_ms("device")
     except Exception as exc:                        # (a box without the memory for the intermediates: report, do not fail the line)
         return {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
     return {"workload": f"xwt and wct(sig=False) of two N=2^{logn} series, dj={dj}: {shape[0]} scales, NumPy in / out (BASELINE config 5 "
                         "without the Monte-Carlo loop, one GPU)", "xwt_ms": x_ms, "wct_ms": w_ms,
+            "xwt_device_ms": xd_ms, "wct_device_ms": wd_ms,
+            "mc_draw_ms_numpy_surrogates": mc_np, "mc_draw_ms": mc_dev,
             "xwt_host_GBs": shape[0] * n * 16 / (x_ms * 1e-3) / 1e9,
-            "includes": "two transforms, smoothing, coherence on the device; download of the result matrices (PCIe-bound)"}
+            "includes": "two transforms, smoothing, coherence on the device; xwt / wct: + download of the result matrices (PCIe-bound); "
+                        "*_device: results left on the GPU; mc_draw_ms: one Monte-Carlo draw of wct_significance for this grid "
+                        "(surrogates of 6 s_max / dt samples, statistical parity only) with surrogates made on the GPU, "
+                        "mc_draw_ms_numpy_surrogates: by NumPy on one host thread (the seed-for-seed default)"}
 
 
 def config4_batch(rt, steps=3):
@@ -707,7 +735,7 @@ def compact_line(out, detail_path):
         short["c4_gs"] = ex["c4_batch"]["value"]
     if "ms_per_call_median" in ex.get("c1_nino3_latency", {}):
         short["c1_ms_per_call"] = ex["c1_nino3_latency"]["ms_per_call_median"]
-    for k in ("xwt_ms", "wct_ms", "mc_draw_ms", "wct_device_ms"):
+    for k in ("xwt_ms", "wct_ms", "wct_device_ms", "mc_draw_ms", "mc_draw_ms_numpy_surrogates"):
         if k in ex.get("c5_xwt_wct", {}):
             short["c5_" + k] = ex["c5_xwt_wct"][k]
     if short:

@@ -82,6 +82,8 @@ SYMBOLS = [
     ("cwt_plan_set_auto_tolerance", C.c_int, [_P, C.c_double]),
     ("cwt_spectrum_range", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("cwt_plan_auto_tolerance", C.c_int, [_P, _P, C.c_double, C.POINTER(C.c_double)]),
+    ("cwt_random_normal", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, _P]),
+    ("cwt_ar1_filter", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_double, _P]),
 ]
 
 
@@ -293,6 +295,18 @@ class Plan:
         v = C.c_double(0)
         self.lib.check(self.lib.cwt_plan_auto_tolerance(self.h, _P(xhat_dev), float(target), C.byref(v)))
         return v.value
+
+    @_locked
+    def random_normal(self, seed: int, offset: int, n: int, scale: float, out_dev: int):
+        """out_dev[0:n] = scale * N(0, 1) made on the device (cwt_random_normal: Philox4x32-10, reproducible per
+        (seed, offset, index))."""
+        self.lib.check(self.lib.cwt_random_normal(self.h, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(n),
+                                                  float(scale), _P(out_dev)))
+
+    @_locked
+    def ar1_filter(self, e_dev: int, tau: int, n: int, g: float, out_dev: int):
+        """out_dev[0:n] = lfilter([1, 0], [1, -g], e)[tau:] for e_dev[0:tau + n] (cwt_ar1_filter)."""
+        self.lib.check(self.lib.cwt_ar1_filter(self.h, _P(e_dev), int(tau), int(n), float(g), _P(out_dev)))
 
     @_locked
     def tolerance(self) -> float:

@@ -754,6 +754,23 @@ int cwt_coherence_histogram(cwt_plan* p, const void* r2_dev, int64_t ld, int nro
 }
 
 
+int cwt_random_normal(cwt_plan* p, uint64_t seed, uint64_t offset, int64_t n, double scale, void* out_dev) {
+  if (!p || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (n < 1) return fail(CWT_EINVAL, "n must be >= 1");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? random_normal_impl<double>(p, seed, offset, n, scale, out_dev)
+                       : random_normal_impl<float>(p, seed, offset, n, scale, out_dev);
+}
+
+int cwt_ar1_filter(cwt_plan* p, const void* e_dev, int64_t tau, int64_t n, double g, void* out_dev) {
+  if (!p || !e_dev || !out_dev) return fail(CWT_EINVAL, "NULL argument");
+  if (n < 1 || tau < 0) return fail(CWT_EINVAL, "need n >= 1 and tau >= 0");
+  if (!(std::fabs(g) < 1.0)) return fail(CWT_EINVAL, "the AR(1) coefficient must be inside (-1, 1)");
+  if (e_dev == out_dev) return fail(CWT_EINVAL, "the filter cannot run in place");
+  HIPCHECK(hipSetDevice(p->device));
+  return p->prec == 64 ? ar1_filter_impl<double>(p, e_dev, tau, n, g, out_dev) : ar1_filter_impl<float>(p, e_dev, tau, n, g, out_dev);
+}
+
 int cwt_forward_fft_n(cwt_plan* p, const void* x_dev, int64_t n0, void* xhat_dev) {
   if (!p || !x_dev || !xhat_dev) return fail(CWT_EINVAL, "NULL argument");
   HIPCHECK(hipSetDevice(p->device));

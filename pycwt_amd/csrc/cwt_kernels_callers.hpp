@@ -316,4 +316,72 @@ __global__ void k_time_mean(const cplx<T>* __restrict__ W, long ldw, long ncols,
   if (threadIdx.x == 0) out[blockIdx.x] = T(part[0] / double(ncols));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Surrogate series of the Monte-Carlo significance (pycwt/wavelet.py:609-613, helpers.py:146-173) made on the device.
+// Philox4x32-10 (Salmon et al. 2011), counter = (index of the pair of outputs, stream offset), key = seed; Box-Muller on two
+// 53-bit uniforms gives two independent N(0, 1) deviates per counter.  Reproducible per (seed, offset, index) and independent
+// of the launch geometry; NOT the sequence of NumPy's generator -- the host path stays the seed-for-seed one.
+struct Philox {
+  unsigned c[4], k[2];
+  __host__ __device__ static inline void mulhilo(unsigned a, unsigned b, unsigned* hi, unsigned* lo) {
+    const unsigned long long p = (unsigned long long)a * (unsigned long long)b;
+    *hi = unsigned(p >> 32);
+    *lo = unsigned(p);
+  }
+  __host__ __device__ inline void round() {
+    unsigned hi0, lo0, hi1, lo1;
+    mulhilo(0xD2511F53u, c[0], &hi0, &lo0);
+    mulhilo(0xCD9E8D57u, c[2], &hi1, &lo1);
+    const unsigned n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  __host__ __device__ inline void run10() {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      round();
+      if (r < 9) { k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u; }
+    }
+  }
+};
+
+// out[i] = scale * N(0, 1), i < n.  Thread t makes outputs 2t and 2t + 1.
+template <typename T>
+__global__ void __launch_bounds__(256) k_normal_fill(unsigned long long seed, unsigned long long offset, long n, double scale,
+                                                     T* __restrict__ out) {
+  const long t = long(blockIdx.x) * 256 + threadIdx.x;
+  if (2 * t >= n) return;
+  Philox g;
+  g.c[0] = unsigned(t); g.c[1] = unsigned((unsigned long long)t >> 32);
+  g.c[2] = unsigned(offset); g.c[3] = unsigned(offset >> 32);
+  g.k[0] = unsigned(seed); g.k[1] = unsigned(seed >> 32);
+  g.run10();
+  // two uniforms in (0, 1]: 53 bits each (u1 never 0: the logarithm is finite)
+  const double u1 = (double((((unsigned long long)g.c[0]) << 21) ^ (g.c[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = double((((unsigned long long)g.c[2]) << 21) ^ (g.c[3] >> 11)) * (1.0 / 9007199254740992.0);
+  const double r = sqrt(-2.0 * log(u1)) * scale, ang = 6.283185307179586476925 * u2;
+  out[2 * t] = T(r * cos(ang));
+  if (2 * t + 1 < n) out[2 * t + 1] = T(r * sin(ang));
+}
+
+// AR(1) filter y[i] = g y[i-1] + e[i] over e[0 .. tau + n) started from y[-1] = 0, the first tau outputs dropped
+// (scipy.signal.lfilter([1, 0], [1, -g], e, axis=0)[tau:], what helpers.py:170 means): out[j] = y[tau + j], j < n.
+// One thread per segment of SEG outputs; it runs the recursion from `warm` samples before its segment -- all the way from
+// e[0] where that is nearer, else far enough that the forgotten history is below g^warm <= 1e-17 of the signal.
+template <typename T>
+__global__ void __launch_bounds__(256) k_ar1_filter(const T* __restrict__ e, long tau, long n, double g, long warm, int seg,
+                                                    T* __restrict__ out) {
+  const long s = (long(blockIdx.x) * 256 + threadIdx.x) * seg;      // first output of this thread
+  if (s >= n) return;
+  const long first = tau + s;                                        // its index in e
+  long i = first - warm;
+  if (i < 0) i = 0;
+  double y = 0;
+  for (; i < first; ++i) y = g * y + double(e[i]);
+  const long end = s + seg < n ? s + seg : n;
+  for (long j = s; j < end; ++j) {
+    y = g * y + double(e[tau + j]);
+    out[j] = T(y);
+  }
+}
+
 }  // namespace cwt

@@ -955,6 +955,28 @@ int transform_rows_n_impl(cwt_plan* p, const void* xhat_dev, int64_t n0, int mot
   return CWT_OK;
 }
 
+// Surrogate series on the device (cwt_random_normal, cwt_ar1_filter)
+template <typename T>
+int random_normal_impl(cwt_plan* p, uint64_t seed, uint64_t offset, int64_t n, double scale, void* out) {
+  const unsigned blocks = unsigned(((n + 1) / 2 + 255) / 256);
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    hipLaunchKernelGGL((k_normal_fill<T>), dim3(blocks), dim3(256), 0, p->stream, (unsigned long long)seed,
+                       (unsigned long long)offset, long(n), scale, static_cast<T*>(out));
+  });
+}
+template <typename T>
+int ar1_filter_impl(cwt_plan* p, const void* e, int64_t tau, int64_t n, double g, void* out) {
+  // history a segment may forget: g^warm <= 1e-17
+  const double lg = std::log(std::fabs(g));
+  const int64_t warm = lg < 0 ? std::min<int64_t>(int64_t(std::ceil(39.2 / -lg)) + 1, tau + n) : tau + n;
+  const int seg = int(std::max<int64_t>(64, std::min<int64_t>(4096, warm / 4)));    // warm-up at most ~4x the useful work
+  const unsigned blocks = unsigned(((n + seg - 1) / seg + 255) / 256);
+  return timed_launch(p, KC_ELEMENTWISE, [&] {
+    hipLaunchKernelGGL((k_ar1_filter<T>), dim3(blocks), dim3(256), 0, p->stream, static_cast<const T*>(e), long(tau), long(n), g,
+                       long(warm), seg, static_cast<T*>(out));
+  });
+}
+
 // ---- one precision per translation unit ----------------------------------------------------------------------------------------
 #define CWT_LAUNCH_TEMPLATES(X, T)                                                                                                  \
   X int build_tables<T>(cwt_plan*);                                                                                                 \
@@ -970,6 +992,8 @@ int transform_rows_n_impl(cwt_plan* p, const void* xhat_dev, int64_t n0, int mot
   X int coherence_impl<T>(cwt_plan*, const void*, const void*, int, int64_t, int64_t, void*);                                       \
   X int reduce_scales_impl<T, true>(cwt_plan*, const void*, int64_t, int64_t, int, const double*, double, void*);                   \
   X int reduce_scales_impl<T, false>(cwt_plan*, const void*, int64_t, int64_t, int, const double*, double, void*);                  \
+  X int random_normal_impl<T>(cwt_plan*, uint64_t, uint64_t, int64_t, double, void*);                                             \
+  X int ar1_filter_impl<T>(cwt_plan*, const void*, int64_t, int64_t, double, void*);                                               \
   X int forward_fft_n_impl<T>(cwt_plan*, const void*, int64_t, void*);                                                              \
   X int transform_rows_n_impl<T>(cwt_plan*, const void*, int64_t, int, double, double, const double*, int, void*, int64_t);
 

@@ -636,6 +636,36 @@ def xwt(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wavelet="mo
     return W12, coi, freq, signif
 
 
+def xwt_device(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wavelet="morlet", normalize=True,
+               *, precision=None, device=0):
+    """`xwt` with the cross spectrum left on the GPU: returns (T, signif) where T is a `DeviceTransform` whose matrix is
+    W1 conj(W2) (`T.W()` downloads it; `T.coi`, `T.freqs` as in `xwt`; `T.close()` frees it).  Built-in mothers, equally long
+    series.  (`xwt` at two 2^20-point series is 47 ms of which ~40 are the download of the 77 x 2^20 complex matrix.)"""
+    mother = _check_parameter_wavelet(wavelet)
+    y1, y2 = np.asarray(y1), np.asarray(y2)
+    if _device_id(mother, strict=False) is None or len(y1) != len(y2):
+        raise ValueError("xwt_device needs a built-in mother and two series of one length")
+    std1, std2 = (1., 1.) if normalize else (y1.std(), y2.std())
+    kw = dict(dj=dj, s0=s0, J=J, wavelet=mother, precision=precision, device=device)
+    T1 = cwt_device(_normalised(y1, normalize), dt, **kw)
+    try:
+        T2 = cwt_device(_normalised(y2, normalize), dt, **kw)
+        try:
+            rows, n0 = T1.shape
+            with T1._plan.lock:
+                T1._plan.cross_spectrum(T1.device_ptr, T2.device_ptr, rows, n0, n0, T1.device_ptr)
+                T1._plan.sync()
+        finally:
+            T2.close()
+    except Exception:
+        T1.close()
+        raise
+    a1, a2 = ar1(y1)[0], ar1(y2)[0]
+    pk = np.sqrt(ar1_spectrum(T1.freqs * dt, a1) * ar1_spectrum(T1.freqs * dt, a2))
+    dof = mother.dofmin
+    return T1, std1 * std2 * pk * chi2.ppf(significance_level, dof) / dof
+
+
 class _Scratch:
     """Device buffers of one wct evaluation, freed together."""
 
@@ -674,11 +704,12 @@ def _smooth_on_device(plan, mother, T, rows, n, dt, dj, sj, spec, tmp, out):
 
 
 def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_angle=True, consume=None,
-                         pool=None, auto=True):
+                         pool=None, auto=True, n0=None, keep=False):
     """|S12|^2/(S1 S2) and arg(W1 conj W2) for two equally long series, all on the GPU; only the two
     real result matrices cross PCIe.  With `consume(plan, r2_buffer, rows, n0)` the coherence stays on the
     device and is handed to that callback instead (Monte-Carlo histogram)."""
-    n0 = len(x1)
+    on_device = isinstance(x1, _hip.DeviceBuffer)           # (surrogates made on the GPU: `n0` says how long they are)
+    n0 = len(x1) if n0 is None else n0
     N = _next_pow2(n0)
     rows = len(sj)
     kind, param = _device_id(mother)
@@ -692,7 +723,16 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
             xd, xh = alloc(n0 * es), alloc(N * 2 * es)
             W1, W2 = alloc(rows * n0 * 2 * es), alloc(rows * n0 * 2 * es)
             target = _auto(plan) if plan.nfft > 4096 and auto else 0.0
-            if target and np.isfinite(x1).all() and np.isfinite(x2).all():
+            if on_device:
+                if target:
+                    tols = []
+                    for x in (x1, x2):
+                        plan.forward_fft(x.ptr, n0, xh.ptr)
+                        tols.append(plan.auto_tolerance(xh.ptr, target))
+                    plan.set_tolerance(min(tols))
+                for x, W in ((x1, W1), (x2, W2)):                 # finite by construction: the signal path (overlap-save rows) applies
+                    plan.transform(x.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, n0, n0)
+            elif target and np.isfinite(x1).all() and np.isfinite(x2).all():
                 # automatic accuracy: ONE tolerance for the pair, the tighter of the two spectra's (a red series paired with
                 # a white one, `surrogates='ar1'` with unlike coefficients); it also stays for the later draws of a
                 # Monte-Carlo loop (auto=False there), whose series come from the same two processes
@@ -702,7 +742,7 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
                     plan.forward_fft(xd.ptr, n0, xh.ptr)
                     tols.append(plan.auto_tolerance(xh.ptr, target))
                 plan.set_tolerance(min(tols))
-            for x, W in ((x1, W1), (x2, W2)):
+            for x, W in (() if on_device else ((x1, W1), (x2, W2))):
                 xh_ = np.ascontiguousarray(x, dtype=plan.real)
                 xd.upload(plan, xh_)
                 _transform(plan, xh_, xd.ptr, n0, kind, param, dt, sj, xh.ptr, W.ptr, auto=False)
@@ -717,12 +757,75 @@ def _coherence_on_device(x1, x2, dt, dj, sj, mother, precision, device, want_ang
                 consume(plan, P, rows, n0)
                 plan.sync()
                 return None, None
+            if keep:                                            # device-resident results: (plan, coherence, angle, scratch to free)
+                plan.sync()
+                return plan, P, ang, sc
             wct_ = P.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False)
             awct = ang.download(plan, (rows, n0), plan.real).astype(np.float64, copy=False) if want_angle else None
             return wct_, awct
     finally:
-        if pool is None:
+        if pool is None and not keep:
             sc.free()
+
+
+class DeviceCoherence:
+    """Result of `wct_device`: the coherence R^2 (rows x n0 reals) and the phase angle stay in GPU memory; `.wct()` /
+    `.angle()` download what the caller asks for, `.close()` frees the device memory.  (`wct(sig=False)` at two 2^20-point
+    series is 58 ms of which ~48 are the download of two 77 x 2^20 matrices; on the device the call is ~10 ms.)"""
+
+    def __init__(self, plan, r2, ang, scratch, shape, coi, freq):
+        self._plan, self._r2, self._ang, self._sc = plan, r2, ang, scratch
+        self.shape, self.coi, self.freq = shape, coi, freq
+
+    @property
+    def wct_ptr(self):
+        return self._r2.ptr
+
+    @property
+    def angle_ptr(self):
+        return self._ang.ptr
+
+    def wct(self):
+        return self._r2.download(self._plan, self.shape, self._plan.real).astype(np.float64, copy=False)
+
+    def angle(self):
+        return self._ang.download(self._plan, self.shape, self._plan.real).astype(np.float64, copy=False)
+
+    def close(self):
+        if self._sc is not None:
+            self._sc.free()
+            self._sc = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def wct_device(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", normalize=True, *, precision=None, device=0):
+    """`wct(..., sig=False)` with the results left on the GPU (a `DeviceCoherence`): both transforms, the smoothing of
+    wavelet.py:499-514 and the coherence ratio as in `wct`, no result matrix crosses PCIe until `.wct()` / `.angle()` is
+    called.  For pipelines that consume the coherence on the device (thresholding, averaging, the Monte-Carlo histogram)."""
+    mother = _check_parameter_wavelet(wavelet)
+    if not hasattr(mother, "deltaj0") or mother.deltaj0 == -1 or not isinstance(mother, Morlet):
+        raise AttributeError("wct needs a mother with a smoothing operator (Morlet), as in the reference")
+    precision = _default_precision() if precision is None else int(precision)
+    y1, y2 = np.asarray(y1), np.asarray(y2)
+    if s0 == -1:
+        s0 = 2 * dt / mother.flambda()
+    if J == -1:
+        J = int(np.round(np.log2(y1.size * dt / s0) / dj))
+    sj = s0 * 2 ** (np.arange(0, J + 1) * dj)
+    plan, r2, ang, sc = _coherence_on_device(_normalised(y1, normalize), _normalised(y2, normalize), dt, dj, sj, mother,
+                                             precision, device, keep=True)
+    return DeviceCoherence(plan, r2, ang, sc, (sj.size, y1.size), _coi(mother, y1.size, dt), 1 / (mother.flambda() * sj))
 
 
 def wct(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, sig=True, significance_level=0.95, wavelet="morlet",
@@ -788,7 +891,7 @@ def _mc_setup(mother, dt, dj, s0, J):
 
 
 def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device, progress=False,
-                  ar1_surrogates=False):
+                  ar1_surrogates=False, rng="numpy", seed=0, first_draw=0):
     """Per-scale histograms (1000 bins on [0, 1)) of the coherence of `draws` AR(1) surrogate pairs, taken
     outside the COI (wavelet.py:609-630).  Coherence AND histogram run on the GPU (`cwt_coherence_histogram`):
     per draw only the two surrogate series go up, and the rows x 1000 counters come down once at the end."""
@@ -815,6 +918,24 @@ def _mc_histogram(draws, al1, al2, dt, dj, sj, N, outside, maxscale, mother, pre
         def count(plan, r2, nrows, n0):
             plan.coherence_histogram(r2.ptr, n0, nrows, lo_d.ptr, hi_d.ptr, max_span, _MC_BINS, hist_d.ptr)
 
+        if rng == "device":
+            # surrogates made on the GPU (cwt_random_normal / cwt_ar1_filter): series 2 k and 2 k + 1 of draw k, nothing
+            # crosses PCIe and no host thread draws 2 N normal deviates per iteration
+            es = np.dtype(plan0.real).itemsize
+            tau = [int(np.ceil(-2 / np.log(np.abs(g)))) if (ar1_surrogates and g != 0) else 0 for g in (al1, al2)]
+            x = [sc.new(N * es), sc.new(N * es)]
+            e = sc.new((N + max(tau)) * es) if max(tau) else None
+            for i in it:
+                k = first_draw + i
+                for w, (g, t) in enumerate(zip((al1, al2), tau)):
+                    if t:
+                        plan0.random_normal(seed, 2 * k + w, N + t, 1.0, e.ptr)
+                        plan0.ar1_filter(e.ptr, t, N, g, x[w].ptr)
+                    else:
+                        plan0.random_normal(seed, 2 * k + w, N, 1.0, x[w].ptr)
+                _coherence_on_device(x[0], x[1], dt, dj, sj, mother, precision, device, want_angle=False, consume=count,
+                                     pool=sc, auto=(i == 0), n0=N)
+            return hist_d.download(plan0, (rows, _MC_BINS), np.uint64).astype(np.float64)
         # the next surrogate pair is drawn on a helper thread while the GPU works on the current one (one
         # worker: the pairs still come from the global NumPy generator in the reference's order)
         from concurrent.futures import ThreadPoolExecutor
@@ -858,7 +979,7 @@ def _mc_cache_path(al1, al2, dt, dj, s0, J, mother, tag=""):
 
 
 def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
-                     progress=True, cache=True, *, precision=None, device=0, surrogates="reference"):
+                     progress=True, cache=True, *, precision=None, device=0, surrogates="reference", rng="numpy", seed=None):
     """Monte-Carlo significance of the coherence (wavelet.py:531-647): `mc_count` pairs of surrogate series,
     coherence of each pair on the GPU, per-scale histogram of the values outside the cone of influence,
     `significance_level` percentile.  Scales that never leave the COI get NaN.
@@ -870,19 +991,34 @@ def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="
     white noise (see `helpers.rednoise`); `surrogates="ar1"` draws the AR(1) processes of lag-1 correlation al1, al2
     that the method calls for, and caches under a different file name.  Results are cached in the reference's file
     format under `get_cache_dir()`.  `pycwt_amd.parallel.wct_significance_sharded` splits the draws over the GPUs of
-    a node."""
+    a node.
+
+    `rng="device"` (opt-in): the surrogates are made on the GPU (Philox4x32-10 + Box-Muller, `cwt_random_normal`; AR(1)
+    filtering by `cwt_ar1_filter` for `surrogates="ar1"`) instead of by NumPy on one host thread, which is 0.10 s of a 0.13 s
+    iteration at two 2^20-point series.  Same distributions, another generator: the levels agree with the NumPy path within
+    the Monte-Carlo error, not seed for seed; `seed` (default: drawn from NumPy's global generator, so `np.random.seed` still
+    pins the result) names the sequence.  Cached under `..._devrng.gz`."""
     if surrogates not in ("reference", "ar1"):
         raise ValueError("surrogates must be 'reference' or 'ar1'")
+    if rng not in ("numpy", "device"):
+        raise ValueError("rng must be 'numpy' or 'device'")
     true_ar1 = surrogates == "ar1"
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
-    path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother, "_ar1" if true_ar1 else "") if cache else None
+    tag = ("_ar1" if true_ar1 else "") + ("_devrng" if rng == "device" else "")
+    path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother, tag) if cache else None
     if cache and os.path.exists(path):
         return np.loadtxt(path, unpack=True)
     N, sj, outside, rows_with_data, maxscale = _mc_setup(mother, dt, dj, s0, J)
-    rednoise(N, al1, 1, ar1=true_ar1)                  # wavelet.py:594: consumed from the RNG before the loop
-    hist = _mc_histogram(mc_count, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device,
-                         progress, ar1_surrogates=true_ar1)
+    if rng == "device":
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(np.random.randint(0, 2 ** 31 - 1))
+        hist = _mc_histogram(mc_count, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device,
+                             progress, ar1_surrogates=true_ar1, rng="device", seed=int(seed))
+    else:
+        rednoise(N, al1, 1, ar1=true_ar1)              # wavelet.py:594: consumed from the RNG before the loop
+        hist = _mc_histogram(mc_count, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device,
+                             progress, ar1_surrogates=true_ar1)
     sig95 = _mc_percentiles(hist, rows_with_data, maxscale, significance_level)
     if cache:
         np.savetxt(path, sig95)

@@ -29,6 +29,18 @@ rows = pycwt_amd.xwt(y1, y2, 1.0, dj)[0].shape[0]
 print(f"N = 2^{logn}, dj = {dj}: {rows} scales.  xwt {t_x * 1e3:.1f} ms ({rows * n * 16 / t_x / 1e9:.1f} GB/s of W12 to the host), "
       f"wct (sig=False) {t_w * 1e3:.1f} ms ({rows * n * 16 / t_w / 1e9:.1f} GB/s of WCT + angle to the host)")
 
+def device_resident(f):
+    r = f(); (r[0] if isinstance(r, tuple) else r).close()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t); (r[0] if isinstance(r, tuple) else r).close()
+    return min(ts)
+
+
+t_xd = device_resident(lambda: pycwt_amd.xwt_device(y1, y2, 1.0, dj))
+t_wd = device_resident(lambda: pycwt_amd.wct_device(y1, y2, 1.0, dj))
+print(f"device-resident results: xwt_device {t_xd * 1e3:.1f} ms, wct_device {t_wd * 1e3:.1f} ms (two uploads of {n * 8 / 1e6:.0f} MB included)")
+
 if len(sys.argv) > 3:                                   # Monte-Carlo significance: draws per second for this scale grid
     mc = int(sys.argv[3])
     from pycwt_amd import wavelet as w
@@ -43,3 +55,11 @@ if len(sys.argv) > 3:                                   # Monte-Carlo significan
     t = time.perf_counter() - t
     print(f"wct_significance for that grid: surrogates of {N} samples x {len(sj)} scales, {mc} draws in {t:.2f} s = "
           f"{t / mc * 1e3:.1f} ms per draw (the reference's default 300 draws: {t / mc * 300:.0f} s on one GPU)")
+    for surr in ("reference", "ar1"):
+        for rng_ in ("numpy", "device"):
+            kw = dict(mc_count=mc, progress=False, cache=False, surrogates=surr, rng=rng_)
+            pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, **dict(kw, mc_count=2))
+            t = time.perf_counter()
+            pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, **kw)
+            t = time.perf_counter() - t
+            print(f"   surrogates={surr!r:12s} rng={rng_!r:9s} {t / mc * 1e3:7.1f} ms per draw")

@@ -198,3 +198,58 @@ def _boxcar_case(lib, precision):
 @pytest.mark.parametrize("precision", [64, 32])
 def test_boxcar_matches_convolve2d(emu_library, precision):
     _boxcar_case(emu_library, precision)
+
+
+def test_device_resident_xwt_and_wct_give_the_host_results(emulated, g):
+    """`wct_device` / `xwt_device`: the same kernels as `wct(sig=False)` / `xwt`, the result matrices left on the GPU until
+    asked for (VERDICT r04 next #7: the download was 50 of the 52 / 61 ms of those calls at two 2^20-point series)."""
+    dt, dj = float(g["dt"]), float(g["dj"])
+    WCT, aWCT, coi, freq, _ = pycwt_amd.wct(g["y1"], g["y2"], dt, dj, -1, -1, False, 0.95, pycwt_amd.Morlet(6), True)
+    with pycwt_amd.wct_device(g["y1"], g["y2"], dt, dj, wavelet=pycwt_amd.Morlet(6)) as D:
+        assert D.shape == WCT.shape and D.wct_ptr and D.angle_ptr
+        assert np.array_equal(D.wct(), WCT) and np.array_equal(D.angle(), aWCT)
+        np.testing.assert_array_equal(D.coi, coi)
+        np.testing.assert_array_equal(D.freq, freq)
+    W12, coi2, freq2, signif = pycwt_amd.xwt(g["y1"], g["y2"], dt, dj=dj, wavelet="morlet")
+    T, signif_d = pycwt_amd.xwt_device(g["y1"], g["y2"], dt, dj=dj, wavelet="morlet")
+    try:
+        assert np.array_equal(T.W(), W12)
+        np.testing.assert_array_equal(T.coi, coi2)
+        np.testing.assert_array_equal(signif_d, signif)
+    finally:
+        T.close()
+    with pytest.raises(ValueError):
+        pycwt_amd.xwt_device(g["y1"], g["y2"][:-1], dt)
+
+
+@pytest.mark.parametrize("surrogates,al", [("reference", (0.3, 0.5)), ("ar1", (0.6, 0.8))])
+def test_wct_significance_with_surrogates_made_on_the_device(emulated, tmp_path, monkeypatch, surrogates, al):
+    """`rng="device"`: Philox surrogates instead of NumPy's.  Another generator, the same distributions: the 95 % levels of
+    250 device draws against 250 NumPy draws of the same problem agree within the Monte-Carlo error (the levels of two
+    independent NumPy runs differ by as much: checked here too, as the yardstick), are reproducible per seed, follow
+    np.random.seed when no seed is given, and cache under their own file name."""
+    from pycwt_amd import wavelet
+    monkeypatch.setattr(wavelet, "get_cache_dir", lambda: str(tmp_path) + "/")
+    kw = dict(dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=250, progress=False, wavelet="morlet", surrogates=surrogates, cache=False)
+    np.random.seed(1)
+    host_a = pycwt_amd.wct_significance(*al, **kw)
+    np.random.seed(2)
+    host_b = pycwt_amd.wct_significance(*al, **kw)
+    dev_a = pycwt_amd.wct_significance(*al, rng="device", seed=11, **kw)
+    dev_b = pycwt_amd.wct_significance(*al, rng="device", seed=12, **kw)
+    ok = np.isfinite(host_a)
+    np.testing.assert_array_equal(np.isnan(dev_a), np.isnan(host_a))
+    yard = max(np.abs(host_a[ok] - host_b[ok]).max(), np.abs(dev_a[ok] - dev_b[ok]).max(), 0.01)
+    assert np.abs(dev_a[ok] - host_a[ok]).max() <= 2.5 * yard, (dev_a, host_a, yard)
+    assert np.abs(0.5 * (dev_a + dev_b)[ok] - 0.5 * (host_a + host_b)[ok]).max() <= 2.0 * yard
+    np.testing.assert_array_equal(pycwt_amd.wct_significance(*al, rng="device", seed=11, **kw), dev_a)      # reproducible
+    assert not np.array_equal(dev_a[ok], dev_b[ok])
+    np.random.seed(5)
+    s1 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=20))
+    np.random.seed(5)
+    s2 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=20))
+    np.testing.assert_array_equal(s1, s2)
+    pycwt_amd.wct_significance(*al, rng="device", seed=3, **dict(kw, mc_count=4, cache=True))
+    assert len(list(tmp_path.glob("wct_sig_*_devrng.gz"))) == 1
+    with pytest.raises(ValueError):
+        pycwt_amd.wct_significance(*al, rng="gpu", **kw)
