@@ -233,11 +233,13 @@ def icwt_sharded(W_local, sj_local, dt, dj=1 / 12, wavelet="morlet", *, group=No
 
 
 def wct_significance_sharded(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="morlet", mc_count=300,
-                             *, group=None, precision=64, device_index=None, seed=None):
+                             *, group=None, precision=64, device_index=None, seed=None, rng="numpy"):
     """Monte-Carlo coherence significance with the surrogate draws split over the ranks:
     every rank simulates ~mc_count/G AR(1) pairs on its GPU, the per-scale histograms (rows x 1000) are
     summed with ONE all-reduce, and every rank evaluates the same percentiles.  Returns the array of
-    `pycwt.wct_significance` (no disk cache here)."""
+    `pycwt.wct_significance` (no disk cache here).  `rng="device"`: the surrogates are made on the GPUs
+    (`cwt_random_normal`): rank r takes the draws r, r + G, ... of ONE Philox sequence named by `seed`, so the result does
+    not depend on the number of ranks."""
     import torch
     import torch.distributed as dist
     from . import wavelet as _w
@@ -251,7 +253,13 @@ def wct_significance_sharded(al1, al2, dt, dj, s0, J, significance_level=0.95, w
         np.random.seed(seed + rank)                       # independent surrogates per rank
     N, sj, outside, rows_with_data, maxscale = _w._mc_setup(mother, dt, dj, s0, J)
     mine = len(range(rank, mc_count, world))
-    hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index)
+    if rng == "device":
+        # contiguous blocks of draws per rank: [first, first + mine) of the one sequence
+        first = sum(len(range(r, mc_count, world)) for r in range(rank))
+        hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index,
+                                rng="device", seed=int(seed or 0), first_draw=first)
+    else:
+        hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index)
     if world > 1:
         backend = dist.get_backend(group)
         t = torch.from_numpy(hist)

@@ -151,6 +151,9 @@ def _mc_worker(rank, world, port, tmpdir):
     _hip._default = _hip.Library(build_emu.build())      # test infrastructure: kernels on the CPU emulation
     sig = parallel.wct_significance_sharded(0.3, 0.5, dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=10, seed=100)
     np.save(os.path.join(tmpdir, f"mc{rank}.npy"), sig)
+    # surrogates made on the device: the ranks take consecutive blocks of ONE Philox sequence
+    sig = parallel.wct_significance_sharded(0.3, 0.5, dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=9, seed=77, rng="device")
+    np.save(os.path.join(tmpdir, f"mcdev{rank}.npy"), sig)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -178,6 +181,11 @@ def test_monte_carlo_draws_sharded_with_one_allreduce(tmp_path):
             np.random.seed(100 + r)
             hist = hist + wavelet._mc_histogram(5, 0.3, 0.5, 1.0, 0.5, sj, N, outside, maxscale, m, 64, 0)
         np.testing.assert_allclose(wavelet._mc_percentiles(hist, rows, maxscale, 0.95), a, equal_nan=True)
+        # device surrogates: 5 + 4 draws on two ranks == the 9 draws of the same sequence on one
+        da, db = np.load(tmp_path / "mcdev0.npy"), np.load(tmp_path / "mcdev1.npy")
+        np.testing.assert_array_equal(da, db)
+        one = wavelet._mc_histogram(9, 0.3, 0.5, 1.0, 0.5, sj, N, outside, maxscale, m, 64, 0, rng="device", seed=77)
+        np.testing.assert_array_equal(wavelet._mc_percentiles(one, rows, maxscale, 0.95), da)
     finally:
         _hip._default = None
         for p in wavelet._plans.values():
