@@ -312,7 +312,15 @@ __global__ void k_aols_gtab(const RowDesc* __restrict__ rows, Mother mo, int log
   const int P = 1 << logP, q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P) return;
   const int kappa = g.ksp + ((q - g.ksp) & (P - 1));
-  const double v = profile_k<double, MK>(mo, rd.a * double(kappa)) * aols_window(g, double(kappa) / double(P));
+  double v;
+  if (MK == MOTHER_PAUL && rd.aux_off == 1) {
+    // continuation through f = 0 (AolsGeom::zc_*): block bins above P/2 are the negative bins
+    const double f = rd.a * double(kappa > (P >> 1) ? kappa - P : kappa);
+    const double arg = (-f - g.zc_c) / g.zc_w;
+    v = arg > 9.0 ? 0.0 : ipow<double>(f, mo.m) * exp(-f) * 0.5 * erfc(arg);      // (erfc(9) / 2 = 2e-37: beyond, exp(-f) may overflow)
+  } else {
+    v = profile_k<double, MK>(mo, rd.a * double(kappa)) * aols_window(g, double(kappa) / double(P));
+  }
   gt[rd.tab_off + q] = T(v * rd.amp_re);
 }
 

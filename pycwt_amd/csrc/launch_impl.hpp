@@ -437,12 +437,40 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   }
   return CWT_OK;
 }
+// The second class of such rows (Paul continued through f = 0, 8192-point tiles; one signal): block spectra of the SAME
+// band-passed signal on its own block grid, then its rows -- on the stream of the first class, behind it (both use p->xsa).
+template <typename T>
+int launch_aols_second(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  const cwt_plan::RowTable* rt = p->rt;
+  const AolsGeom& g = rt->aols2_geom;
+  constexpr int LOGP = 13, P = 1 << LOGP;
+  int rc = grow(&p->xsa, &p->xsa_bytes, size_t(g.nblocks) * size_t(P + 8) * sizeof(cplx<T>), st);
+  if (rc) return rc;
+  static const bool once = (allow_big_lds(&k_aols_fwd<T, LOGP>), allow_big_lds(&k_aols_rows<T, LOGP>), true);
+  (void)once;
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), 1u), dim3(1 << (LOGP - 4)), lds, st,
+                       static_cast<const cplx<T>*>(p->xm), p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all),
+                       static_cast<cplx<T>*>(p->xsa));
+  }, st);
+  if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
+    hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols2_wgs), 1u), dim3(1 << (LOGP - 4)), lds, st,
+                       static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols2_first, static_cast<const T*>(rt->agt_dev),
+                       static_cast<const cplx<T>*>(p->tw_all), g, static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W,
+                       long(ldw), long(ncols));
+  }, st);
+  return rc;
+}
 template <typename T>
 int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+  int rc = CWT_OK;
   switch (p->rt->aols_logp) {
-    case 12: return launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st);
+    case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st); break;
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
+  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, st);
+  return rc;
 }
 
 // Band-limited rows in polynomial form: the filtered bands and the interval coefficients (k_poly_band, k_poly_coef) ...
@@ -761,6 +789,9 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
   else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
   else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
+  if (t->n_aols2)      // the second class (Paul, 8192-point tiles): its rows carry the offsets of their tables behind the first's
+    hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), dim3((1 << 13) / 256, t->aols2_geom.nrows), block, 0, p->stream,
+                       t->rows_dev + t->aols2_first, mo, 13, t->aols2_geom, gt);
   HIPCHECK(hipGetLastError());
   return CWT_OK;
 }

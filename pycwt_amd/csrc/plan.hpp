@@ -100,6 +100,7 @@ struct cwt_plan {
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
                            // HIP graph on its second occurrence and replay it from the third on
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
+  int aols_zc = 1;         // Paul rows not clipped at Nyquist on the band-passed signal too, their profile continued through f = 0
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
@@ -187,6 +188,10 @@ struct cwt_plan {
     int aols_nbatch = 1;                 // signals of a batched call: aols_geom.nrows rows and one mask pseudo-row (aux_first + b) each
     cwt::AolsGeom aols_geom{};
     long aols_wgs = 0, aols_gt_elems = 0;
+    // second class of such rows (Paul continued through f = 0, 8192-point tiles): n_aols2 of the n_aols rows, at aols2_first
+    int n_aols2 = 0, aols2_first = 0;
+    cwt::AolsGeom aols2_geom{};
+    long aols2_wgs = 0;
     void* agt_dev = nullptr;             // their (real) filter tables
     size_t agt_bytes = 0;
     cwt::RowDesc* rows_dev = nullptr;

@@ -347,6 +347,67 @@ int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps
   return best;
 }
 
+// The same search for a Paul row continued through f = 0 (AolsGeom::zc_c / zc_w, k_aols_gtab): e = IFFT(E),
+// E(kappa) = f^m e^-f erfc((-f - c) / w) / 2 at f = aN kappa / n over the signed bins kappa in [-n/2, n/2).  The tail is
+// measured against the L1 mass of the TRUE wavelet (positive bins only): the continuation's lobe below 0 is up to `amp`
+// times larger than the filter itself and dominates the kernel's own mass, but the band-passed signal has nothing there.
+// Returns 0 if no halo <= hmax qualifies; *amp = max|E| / max of the true filter (what rounding noise is multiplied by).
+int aols_halo_zc(int m, double aN, double c, double w, double eps, int hmax, double* amp, int* exact = nullptr) {
+  const int n = 4 * hmax;
+  std::vector<std::complex<double>> e(static_cast<size_t>(n), std::complex<double>(0.0, 0.0));
+  std::vector<std::complex<double>> t(static_cast<size_t>(n), std::complex<double>(0.0, 0.0));
+  double emax = 0, tmax = 0;
+  for (int q = 0; q < n; ++q) {
+    const int kappa = q > n / 2 ? q - n : q;
+    const double f = aN * double(kappa) / double(n);
+    const double arg = (-f - c) / w;
+    const double g = std::pow(f, m) * std::exp(-std::max(f, -700.0));
+    const double v = arg > 9.0 ? 0.0 : g * 0.5 * std::erfc(arg);
+    e[size_t(q)] = v;
+    t[size_t(q)] = kappa > 0 && q != n / 2 ? g : 0.0;
+    emax = std::max(emax, std::fabs(v));
+    tmax = std::max(tmax, std::fabs(t[size_t(q)].real()));
+  }
+  if (!(tmax > 0)) return 0;
+  *amp = emax / tmax;
+  host_ifft(e);
+  host_ifft(t);
+  double total = 0;
+  for (int i = 0; i < n; ++i) total += std::abs(t[size_t(i)]);
+  std::vector<double> ring(size_t(n / 2) + 1, 0.0);
+  for (int i = 0; i < n; ++i) ring[size_t(std::min(i, n - i))] += std::abs(e[size_t(i)]);
+  double tail = 0;
+  int best = 0;
+  for (int d = n / 2; d > 0; --d) {
+    tail += ring[size_t(d)];
+    if (tail > eps * total) break;
+    if (exact) *exact = d - 1;
+    if ((d - 1) % 64 == 0 && d - 1 >= 64 && d - 1 <= hmax) best = d - 1;
+  }
+  return best;
+}
+
+// The halo of such a row is its scale times a constant as long as the filter has died out long before Nyquist (the kernel is
+// the same function of t / s): the constant, from one search at a scale of 100 samples, kept per (m, c, w, eps).
+double zc_halo_factor(int m, double c, double w, double eps) {
+  struct Entry { int m; double c, w, eps, value; };
+  static std::mutex mu;
+  static std::vector<Entry> memo;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : memo) if (e.m == m && e.c == c && e.w == w && e.eps == eps) return e.value;
+  }
+  double amp = 0;
+  int exact = 0;
+  const double s_ref = 100.0;
+  (void)aols_halo_zc(m, 2.0 * 3.14159265358979323846 * s_ref, c, w, eps, 4096, &amp, &exact);
+  const double v = exact > 0 ? double(exact) / s_ref : 0.0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (memo.size() >= 32) memo.erase(memo.begin());
+  memo.push_back({m, c, w, eps, v});
+  return v;
+}
+
 // z with erfc(z) / 2 = tail
 double erfc_arg(double tail) {
   double lo = 0, hi = 10;
@@ -480,7 +541,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   double fc_lo = 0, fc_hi = 0;
   if (ols_ok || aols_ok) profile_support(mother, param, tol.clip, &fc_lo, &fc_hi);
   std::vector<RowDesc> narrow_rows, wide_rows, small_rows, poly_rows;
-  std::vector<char> wide_clipped;
+  std::vector<char> wide_clipped, wide_unclipped;
   const bool poly_ok = p->poly && p->use_ct && logP == (p->prec == 64 ? 13 : 14) && mother != MOTHER_TABLE &&
                        p->logN >= std::max(POLY_LOGP, p->poly_min_logn) && !use_small && rows_per_signal == 0;   // (not for batches yet)
   struct OlsRow { RowDesc rd; int grp, lb, h64; };
@@ -643,19 +704,37 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         wide_rows.push_back(rd);
         wide_clipped.push_back(aols_ok && !vanishes && rd.nband > 0 &&
                                (mother == MOTHER_DOG ? (amp_re[j] == 0.0) != (amp_im[j] == 0.0) : amp_im[j] == 0.0));
+        wide_unclipped.push_back(aols_ok && vanishes && rd.nband > 0 && amp_im[j] == 0.0);
       }
     }
   }
   // Rows clipped at Nyquist (so far two-pass rows) that can run as overlap-save rows on the band-passed complex signal:
   // one mask and one window for all of them (from the smallest scale), the halo of each from its kernel, one halo class.
-  std::vector<RowDesc> aols_rows;
-  AolsGeom ag{};
+  std::vector<RowDesc> aols_rows, aols2_rows;
+  AolsGeom ag{}, ag2{};
   int aols_logp = 12, aols_ks = 1;
+  // Paul rows whose filter has died out at Nyquist (two-pass rows so far: the kink of f^m H(f) at f = 0 gives the wavelet its
+  // 1/t^(m+1) tail, a halo of ~250 scales at 1e-10): the profile continued THROUGH f = 0 and cut below it by a taper of the
+  // row's own width (AolsGeom::zc_*, k_aols_gtab).  Taper centre c, width c / 6 (u(0) = 1 - 1e-17).  The lobe below 0 is
+  // ~c^m e^c / (2 m^m e^-m) times the filter; the band-passed signal has nothing there but rounding noise, so that factor times
+  // the arithmetic's epsilon must stay a tenth of the accuracy target: c = 4 in fp64 at 1e-9 (x 1.5e3), not available in fp32.
+  const int paul_m = int(std::lround(param));
+  double zc_c = 0;
+  if (aols_ok && p->aols_zc && mother == MOTHER_PAUL && paul_m >= 1 && rows_per_signal == 0) {
+    const double mach = p->prec == 64 ? 1.2e-16 : 6e-8;
+    const double budget = 0.1 * std::max(tol.clip, 10 * mach) / mach;
+    const double peak = std::pow(double(paul_m), paul_m) * std::exp(-double(paul_m));
+    for (double c : {4.0, 3.5, 3.0, 2.5, 2.0})
+      if (std::pow(c, paul_m) * std::exp(c) * 0.5 / peak <= budget) { zc_c = c; break; }
+  }
   if (aols_ok) {
     double a_min = 0;
-    for (size_t i = 0; i < wide_rows.size(); ++i)
+    bool any_zc = false;
+    for (size_t i = 0; i < wide_rows.size(); ++i) {
       if (wide_clipped[i] && (a_min == 0 || wide_rows[i].a < a_min)) a_min = wide_rows[i].a;
-    bool geom_ok = a_min > 0;
+      any_zc = any_zc || (zc_c > 0 && wide_unclipped[i]);
+    }
+    bool geom_ok = a_min > 0 || any_zc;
     if (geom_ok) {
       ag.z = erfc_arg(std::max(tol.halo * 0.1, 1e-19));
       if (mother == MOTHER_MORLET) {
@@ -680,22 +759,49 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         aols_ks = 1;
       }
     }
-    std::vector<int> halos(wide_rows.size(), 0);
-    int hmax_seen = 0, cnt = 0;
+    std::vector<int> halos(wide_rows.size(), 0), halos2(wide_rows.size(), 0);
+    std::vector<char> zc_row(wide_rows.size(), 0);
+    int hmax_seen = 0, hmax2_seen = 0, cnt = 0, cnt2 = 0;
     const int rps = rows_per_signal > 0 ? rows_per_signal : nrows;
     if (geom_ok) {
       const double eps = std::max(tol.halo, p->prec == 64 ? 2e-14 : 5e-7);
       std::vector<int> halo_of_scale(size_t(rps), -1);     // (a numeric tail search each: once per scale, not per signal)
       const std::vector<double> window = aols_window_grid(ag, 512);
+      ag.zc_c = ag2.zc_c = zc_c;
+      ag.zc_w = ag2.zc_w = zc_c / 6.0;
+      double zc_f_safe = 0, zc_factor = 0, zc_dummy = 0;
+      if (zc_c > 0) {
+        profile_support(MOTHER_PAUL, param, eps * 1e-3, &zc_dummy, &zc_f_safe);
+        zc_factor = zc_halo_factor(paul_m, ag.zc_c, ag.zc_w, eps);
+      }
       for (size_t i = 0; i < wide_rows.size(); ++i) {
+        if (zc_c > 0 && wide_unclipped[i]) {               // continued through f = 0: 4096-point tiles up to a halo of 512,
+          double amp = 0;                                  // 8192-point tiles up to 2048 (a second class, below)
+          // scale-invariant halo where the filter has died out far below eps long before Nyquist, the numeric search otherwise
+          int h = 0;
+          const double aN = wide_rows[i].a * double(N);
+          if (0.5 * aN > zc_f_safe && zc_factor > 0) {
+            const double want = zc_factor * aN / (2.0 * 3.14159265358979323846) * 1.01 + 2.0;
+            h = want <= 2048.0 ? std::max(64, int((int64_t(std::ceil(want)) + 63) / 64 * 64)) : 0;
+          } else {
+            h = aols_halo_zc(paul_m, aN, ag.zc_c, ag.zc_w, eps, 2048, &amp);
+          }
+          if (h > 0 && h <= 512) { halos[i] = h; zc_row[i] = 1; ++cnt; hmax_seen = std::max(hmax_seen, h); }
+          else if (h > 512) { halos2[i] = h; zc_row[i] = 1; ++cnt2; hmax2_seen = std::max(hmax2_seen, h); }
+          continue;
+        }
         if (!wide_clipped[i]) continue;
         int& h = halo_of_scale[size_t(wide_rows[i].out_row % rps)];
         if (h < 0) h = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512, window);
         halos[i] = h;
         if (halos[i]) { ++cnt; hmax_seen = std::max(hmax_seen, halos[i]); }
       }
+      if (cnt2 && !cnt) {                                  // (the second class rides on the first one's band-passed signal: keep
+        cnt2 = 0;                                          // the layout simple -- no first class, no second)
+        std::fill(halos2.begin(), halos2.end(), 0);
+      }
     }
-    if (geom_ok && cnt % aols_nbatch == 0 && cnt / aols_nbatch >= std::max(1, p->aols_min_rows)) {
+    if (geom_ok && cnt % aols_nbatch == 0 && (cnt + cnt2) / aols_nbatch >= std::max(1, p->aols_min_rows) && cnt > 0) {
       aols_logp = 12;                                      // 4096-point tiles: four block transforms in flight per CU
       const int P = 1 << aols_logp, L = P - 2 * hmax_seen;
       ag.halo = hmax_seen;
@@ -705,7 +811,29 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       std::vector<RowDesc> keep;
       long toff = 0;
       std::vector<long> tab_of_scale(size_t(rps), -1);     // one filter table per scale, shared by the signals
+      // the second class: 8192-point tiles, its own halo / block grid, its tables behind the first class's
+      const int P2 = 1 << 13, L2 = P2 - 2 * hmax2_seen;
+      ag2.f_s = ag.f_s; ag2.f1_lo = ag.f1_lo; ag2.z = ag.z;
+      ag2.halo = hmax2_seen;
+      ag2.nrows = cnt2;
+      ag2.nblocks = cnt2 ? int((out_ncols + L2 - 1) / L2) : 0;
+      ag2.ksp = int(std::ceil(ag2.f_s * double(P2)));
+      long toff2 = long(ag.nrows) << aols_logp;
       for (size_t i = 0; i < wide_rows.size(); ++i) {
+        if (halos2[i]) {
+          RowDesc o = wide_rows[i];
+          o.a = wide_rows[i].a * double(N >> 13);
+          o.amp_re = amp_re[o.out_row] / double(P2);
+          o.amp_im = 0.0;
+          o.k_lo = ag2.ksp; o.nband = P2;
+          o.logK = 13; o.nterms = 1;
+          o.nyq_re = o.nyq_im = 0.0;
+          o.aux_off = 1;
+          o.tab_off = toff2;
+          toff2 += P2;
+          aols2_rows.push_back(o);
+          continue;
+        }
         if (!halos[i]) { keep.push_back(wide_rows[i]); continue; }
         RowDesc o = wide_rows[i];
         o.a = wide_rows[i].a * double(N >> aols_logp);     // profile argument per block bin
@@ -714,6 +842,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         o.k_lo = ag.ksp; o.nband = P;
         o.logK = aols_logp; o.nterms = 1;
         o.nyq_re = o.nyq_im = 0.0;
+        o.aux_off = zc_row[i] ? 1 : 0;
         if (mother == MOTHER_DOG) {
           const int mm = int(std::lround(param));
           const bool odd = (mm & 1) != 0;
@@ -887,6 +1016,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   p->rt->n_aols = int(aols_rows.size());
   p->rt->aux_first = -1;
   p->rt->aols_gt_elems = 0;
+  p->rt->n_aols2 = 0;
   if (!aols_rows.empty()) {
     p->rt->table.insert(p->rt->table.end(), aols_rows.begin(), aols_rows.end());
     p->rt->aols_logp = aols_logp;
@@ -894,6 +1024,16 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     p->rt->aols_wgs = long((ag.nblocks + 7) / 8) * 8 * ag.nrows;
     p->rt->aols_gt_elems = long(ag.nrows) << aols_logp;
     p->rt->aols_nbatch = aols_nbatch;
+    // second class (Paul rows continued through f = 0 on 8192-point tiles): right behind the first in the table
+    p->rt->aols2_first = int(p->rt->table.size());
+    p->rt->n_aols2 = int(aols2_rows.size());
+    p->rt->n_aols += p->rt->n_aols2;
+    if (!aols2_rows.empty()) {
+      p->rt->table.insert(p->rt->table.end(), aols2_rows.begin(), aols2_rows.end());
+      p->rt->aols2_geom = ag2;
+      p->rt->aols2_wgs = long((ag2.nblocks + 7) / 8) * 8 * ag2.nrows;
+      p->rt->aols_gt_elems += long(ag2.nrows) << 13;
+    }
     RowDesc m{};                                          // (zero-initialised: no Nyquist term) the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)
     m.a = 0.0; m.amp_re = 1.0 / double(N); m.amp_im = 0.0;
     m.k_lo = aols_ks; m.nband = int(N / 2) - aols_ks;
