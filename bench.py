@@ -751,7 +751,7 @@ def compact_line(out, detail_path):
     return rnd(line)
 
 
-def measure(rt, config, args, rows_total, opts, want_cpu):
+def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True):
     wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
     if args.prime and not args.emulate:
         # the same W + K steps first from an idle device (reported as `from_idle`), then with the clocks up (the headline)
@@ -769,7 +769,7 @@ def measure(rt, config, args, rows_total, opts, want_cpu):
         out = wl.timed(args.steps, args.warmup)
         out["effective_warmup_steps"] = args.warmup
     traffic = None
-    if (args.live_traffic and not args.emulate and not wl.sharded and not rt.use_dist and not args.shard and want_cpu
+    if (args.live_traffic and traffic_passes and not args.emulate and not wl.sharded and not rt.use_dist and not args.shard and want_cpu
             and set(wl.opts) <= {"tolerance"} and wl.tolerance == BENCH_TOLERANCE[wl.prec]):
         # (the config-3 blocks of the default run too: round 4 read theirs from committed files)
         split = wl.plan.last_split()
@@ -910,9 +910,11 @@ def main():
         out["extra"]["c1_nino3_latency"] = config1_latency()
         out["extra"]["c4_batch"] = config4_batch(rt)
         out["extra"]["c5_xwt_wct"] = config5_callers()
-        for c in ("c3_paul", "c3_dog"):
-            r = measure(rt, c, args, rows_total, {}, want_cpu=True)
-            out["extra"][c] = {"workload": f"N=2^{args.logn} {r['label']} {rows_total} scales (BASELINE config 3)",
+        for c in ("c3_paul", "c3_dog", "paul64"):
+            # (paul64: not a BASELINE config -- config 3 is quoted in fp32 -- but the reference's own arithmetic for Paul,
+            # mothers.py:118-122, and what pycwt_amd.cwt(..., 'paul') runs by default; parity on the rows the reference keeps)
+            r = measure(rt, c, args, rows_total, {}, want_cpu=True, traffic_passes=c != "paul64")
+            out["extra"][c] = {"workload": f"N=2^{args.logn} {r['label']} {rows_total} scales" + (" (BASELINE config 3)" if c != "paul64" else ""),
                                "value": r["value"], "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"],
                                "dtype": r["dtype"], "steps": args.steps, "warmup": args.warmup, "tolerance": r["tolerance"],
                                "roofline": r["roofline"], "parity": r["parity"], "cpu_baseline": r["cpu_baseline"],

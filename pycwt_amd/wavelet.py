@@ -450,10 +450,13 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
     finally:
         xd.free()
         xh.free()
-    if not user_freqs:
-        freqs = np.array(freqs)                 # (cached grids stay private, as in cwt())
-    return DeviceTransform(plan, Wd, np.array(sj), freqs, np.array(coi), xhat[1:N // 2] / N ** 0.5, np.array(fftfreqs),
-                           mother, dt, n0)
+    # (the cached grids are handed out as READ-ONLY views here, not copied as in cwt(): at 2^20 points the copies of coi and
+    # fftfreqs -- 12 MB of fresh pages per call -- cost more than the transform; profiles/r05_wct.txt)
+    def ro(a):
+        v = np.asarray(a).view()
+        v.flags.writeable = False
+        return v
+    return DeviceTransform(plan, Wd, ro(sj), ro(freqs), ro(coi), xhat[1:N // 2] / N ** 0.5, ro(fftfreqs), mother, dt, n0)
 
 
 def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
