@@ -318,6 +318,13 @@ __global__ void k_aols_gtab(const RowDesc* __restrict__ rows, Mother mo, int log
     const double f = rd.a * double(kappa > (P >> 1) ? kappa - P : kappa);
     const double arg = (-f - g.zc_c) / g.zc_w;
     v = arg > 9.0 ? 0.0 : ipow<double>(f, mo.m) * exp(-f) * 0.5 * erfc(arg);      // (erfc(9) / 2 = 2e-37: beyond, exp(-f) may overflow)
+    if (kappa > (P >> 1)) {
+      // a row whose filter has not died out at Nyquist: ALSO continued past Nyquist and tapered to nothing by 3/4 cycle per
+      // sample (the host only accepts the row if the taper below 0 starts above that: a s w_N > 4 (c + 6 w))
+      const double fc = double(kappa) / double(P);
+      const double up = profile_k<double, MK>(mo, rd.a * double(kappa)) * 0.5 * erfc(g.z * (fc - 0.625) / 0.125);
+      v += fc < 0.76 ? up : 0.0;
+    }
   } else {
     v = profile_k<double, MK>(mo, rd.a * double(kappa)) * aols_window(g, double(kappa) / double(P));
   }

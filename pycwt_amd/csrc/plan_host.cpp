@@ -352,8 +352,9 @@ int aols_halo(int mother, double param, double aN, const AolsGeom& g, double eps
 // measured against the L1 mass of the TRUE wavelet (positive bins only): the continuation's lobe below 0 is up to `amp`
 // times larger than the filter itself and dominates the kernel's own mass, but the band-passed signal has nothing there.
 // Returns 0 if no halo <= hmax qualifies; *amp = max|E| / max of the true filter (what rounding noise is multiplied by).
-int aols_halo_zc(int m, double aN, double c, double w, double eps, int hmax, double* amp, int* exact = nullptr) {
+int aols_halo_zc(int m, double aN, double c, double w, double eps, int hmax, double* amp, int* exact = nullptr, double z = 0) {
   const int n = 4 * hmax;
+  if (z > 0 && !(aN > 4.0 * (c + 6.0 * w))) return 0;      // the two continuations would overlap above Nyquist
   std::vector<std::complex<double>> e(static_cast<size_t>(n), std::complex<double>(0.0, 0.0));
   std::vector<std::complex<double>> t(static_cast<size_t>(n), std::complex<double>(0.0, 0.0));
   double emax = 0, tmax = 0;
@@ -362,7 +363,11 @@ int aols_halo_zc(int m, double aN, double c, double w, double eps, int hmax, dou
     const double f = aN * double(kappa) / double(n);
     const double arg = (-f - c) / w;
     const double g = std::pow(f, m) * std::exp(-std::max(f, -700.0));
-    const double v = arg > 9.0 ? 0.0 : g * 0.5 * std::erfc(arg);
+    double v = arg > 9.0 ? 0.0 : g * 0.5 * std::erfc(arg);
+    if (z > 0 && q > n / 2) {                               // continued past Nyquist too (k_aols_gtab)
+      const double fc = double(q) / double(n), fu = aN * fc;
+      if (fc < 0.76) v += std::pow(fu, m) * std::exp(-fu) * 0.5 * std::erfc(z * (fc - 0.625) / 0.125);
+    }
     e[size_t(q)] = v;
     t[size_t(q)] = kappa > 0 && q != n / 2 ? g : 0.0;
     emax = std::max(emax, std::fabs(v));
@@ -775,6 +780,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         zc_factor = zc_halo_factor(paul_m, ag.zc_c, ag.zc_w, eps);
       }
       for (size_t i = 0; i < wide_rows.size(); ++i) {
+        const bool zc_clipped = zc_c > 0 && wide_clipped[i] && wide_rows[i].a * double(N) > 4.0 * (ag.zc_c + 6.0 * ag.zc_w);
+        if (zc_clipped) {                                  // filter alive at Nyquist AND room for both continuations
+          double amp = 0;
+          const int h = aols_halo_zc(paul_m, wide_rows[i].a * double(N), ag.zc_c, ag.zc_w, eps, 2048, &amp, nullptr, ag.z);
+          if (h > 0 && h <= 512) { halos[i] = h; zc_row[i] = 1; ++cnt; hmax_seen = std::max(hmax_seen, h); continue; }
+          if (h > 512) { halos2[i] = h; zc_row[i] = 1; ++cnt2; hmax2_seen = std::max(hmax2_seen, h); continue; }
+        }
         if (zc_c > 0 && wide_unclipped[i]) {               // continued through f = 0: 4096-point tiles up to a halo of 512,
           double amp = 0;                                  // 8192-point tiles up to 2048 (a second class, below)
           // scale-invariant halo where the filter has died out far below eps long before Nyquist, the numeric search otherwise

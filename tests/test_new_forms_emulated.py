@@ -238,3 +238,33 @@ def test_polynomial_rows_in_chunks_of_bounded_coefficient_volume(emu_library, pr
         W, s2, _ = transform(emu_library, N, x, orc.MORLET, 6, sj, prec, {"poly_chunk_mb": mb})
         assert s2 == split
         np.testing.assert_array_equal(W, base)
+
+
+def test_paul_rows_continued_through_zero_frequency(emu_library, monkeypatch):
+    """Round 5, form A for fp64 Paul: rows whose wavelet's 1/t^5 tail (the kink of f^m H(f) at f = 0) left them to the two-pass
+    fallback run on the band-passed signal with the profile continued analytically THROUGH f = 0 and cut by a taper of the
+    row's own width (AolsGeom::zc_*): two tile sizes, also the rows still alive at Nyquist where both continuations fit.
+    Every row -- the reference's NaN rows included -- against the intended-value oracle at the accuracy target; the form is
+    off at round-off (its price is 1.5e3 x eps of rounding noise) and in fp32."""
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    N = 1 << 17
+    n0 = N - 91
+    m = orc.Mother(orc.PAUL, 4)
+    s0 = 2 / m.flambda()
+    sj = s0 * 2 ** (np.arange(96) * np.log2(n0 / s0) / 95)                      # (no rows dropped: the oracle below has them all)
+    x = np.random.default_rng(77).standard_normal(n0)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N, intended=True)[:, :n0]
+    opts = {"ols_min_logn": 15, "poly_min_logn": 15}
+    W, split, classes = transform(emu_library, N, x, orc.PAUL, 4, sj, 64, dict(opts, tolerance=1e-9))
+    W0, split0, classes0 = transform(emu_library, N, x, orc.PAUL, 4, sj, 64, dict(opts, tolerance=1e-9, aols_zc=0))
+    assert split["aols"] >= split0["aols"] + 15 and split["two_pass"] <= split0["two_pass"] - 15, (split, split0)
+    assert any(c == "aols/P8192" for c in classes) and any(c == "aols/P4096" for c in classes)
+    per_row = row_errors(W, ref)[0]
+    assert per_row.max() < 1e-9, (per_row.argmax(), classes[per_row.argmax()], per_row.max())
+    moved = [j for j, (a, b) in enumerate(zip(classes, classes0)) if a.startswith("aols") and not b.startswith("aols")]
+    assert per_row[moved].max() < 1e-10                                           # measured 8e-12: the lobe below 0 costs 1.5e3 x eps
+    assert row_errors(W0, ref)[0].max() < 1e-9
+    # not at round-off, not in complex64
+    for prec, tol in ((64, 1e-16), (32, 3e-5)):
+        _, s2, c2 = transform(emu_library, N, x, orc.PAUL, 4, sj, prec, dict(opts, tolerance=tol))
+        assert not any(c == "aols/P8192" for c in c2), (prec, s2)
