@@ -290,9 +290,9 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
 int cwt_plan_set_tolerance(cwt_plan* p, double rel_tol) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   if (!(rel_tol >= 0) || rel_tol > 1e-2) return fail(CWT_EINVAL, "tolerance must be in [0, 1e-2] (0 = default)");
-  for (auto& t : p->slots) t.key.clear();   // the classification depends on it
-  p->tolerance = rel_tol;
-  return CWT_OK;
+  if (rel_tol != p->tolerance) for (auto& t : p->slots) t.key.clear();   // the classification depends on it (an unchanged value
+  p->tolerance = rel_tol;                                                  // keeps the cached row tables: a Monte-Carlo loop
+  return CWT_OK;                                                           // re-measures it at its first draw)
 }
 
 int cwt_plan_set_auto_tolerance(cwt_plan* p, double target) {

@@ -373,16 +373,30 @@ class DeviceTransform:
     resident; the reductions every caller of `cwt` does next -- power, global spectrum, scale
     averages, reconstruction -- run there and only vectors cross PCIe.  `W()` downloads the matrix."""
 
-    def __init__(self, plan, buf, sj, freqs, coi, fft, fftfreqs, mother, dt, n0):
+    def __init__(self, plan, buf, sj, freqs, coi, fft, fftfreqs, mother, dt, n0, spectrum=None):
         self._plan, self._buf = plan, buf
-        self.sj, self.freqs, self.coi, self.fft, self.fftfreqs = sj, freqs, coi, fft, fftfreqs
+        self.sj, self.freqs, self.coi, self.fftfreqs = sj, freqs, coi, fftfreqs
+        self._fft, self._spectrum = fft, spectrum              # the 5th return value of cwt(): downloaded when first asked for
         self.mother, self.dt, self.n0 = mother, dt, n0
         self.shape = (sj.size, n0)
+
+    @property
+    def fft(self):
+        if self._fft is None and self._spectrum is not None:
+            N = self._plan.nfft
+            xhat = self._spectrum.download(self._plan, (N,), self._plan.cplx).astype(np.complex128)
+            self._fft = xhat[1:N // 2] / N ** 0.5
+            self._spectrum.free()
+            self._spectrum = None
+        return self._fft
 
     def close(self):
         if self._buf is not None:
             self._buf.free()
             self._buf = None
+        if self._spectrum is not None:
+            self._spectrum.free()
+            self._spectrum = None
 
     __del__ = close
 
@@ -443,20 +457,20 @@ def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None,
             xs_host = np.ascontiguousarray(signal, dtype=plan.real)
             xd.upload(plan, xs_host)
             _transform(plan, xs_host, xd.ptr, n0, kind, param, dt, sj, xh.ptr, Wd.ptr)
-            xhat = xh.download(plan, (N,), plan.cplx).astype(np.complex128)
+            plan.sync()
     except Exception:
         Wd.free()
+        xh.free()
         raise
     finally:
         xd.free()
-        xh.free()
     # (the cached grids are handed out as READ-ONLY views here, not copied as in cwt(): at 2^20 points the copies of coi and
     # fftfreqs -- 12 MB of fresh pages per call -- cost more than the transform; profiles/r05_wct.txt)
     def ro(a):
         v = np.asarray(a).view()
         v.flags.writeable = False
         return v
-    return DeviceTransform(plan, Wd, ro(sj), ro(freqs), ro(coi), xhat[1:N // 2] / N ** 0.5, ro(fftfreqs), mother, dt, n0)
+    return DeviceTransform(plan, Wd, ro(sj), ro(freqs), ro(coi), None, ro(fftfreqs), mother, dt, n0, spectrum=xh)
 
 
 def cwt_batch(signals, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None,
