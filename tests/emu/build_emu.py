@@ -27,14 +27,17 @@ def build(force=False):
     flags = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-DCWT_BACKEND_NAME=\"cpu-emulation\"",
              "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
-    def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".emu.o")
+    def compile_one(src):          # (object names carry the pid: pytest-xdist workers may build side by side)
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + f".{os.getpid()}.emu.o")
         subprocess.run(["g++"] + flags + ["-x", "c++", "-c", src, "-o", obj], check=True)
         return obj
     with ThreadPoolExecutor(max_workers=len(SRCS)) as pool:
         objs = list(pool.map(compile_one, SRCS))
-    subprocess.run(["g++", "-shared", "-pthread"] + objs + ["-o", OUT + ".tmp"], check=True)
-    os.replace(OUT + ".tmp", OUT)
+    tmp = OUT + f".tmp{os.getpid()}"
+    subprocess.run(["g++", "-shared", "-pthread"] + objs + ["-o", tmp], check=True)
+    os.replace(tmp, OUT)
+    for o in objs:
+        os.remove(o)
     return OUT
 
 
