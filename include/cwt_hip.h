@@ -77,6 +77,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "aols"         0 = rows clipped at the Nyquist bins stay two-pass rows (default 1: overlap-save rows on the band-passed
  *                  complex signal, k_aols_*; Morlet, Paul, and -- with the real signal at hand -- DOG of order >= 1)
  *   "aols_min_rows" ... if at least this many rows qualify (default 3: the band-passed signal costs about one two-pass row)
+ *   "aols_zc"      0 = fp64 Paul rows whose filter has died out at Nyquist stay two-pass rows (default 1: they run on the
+ *                  band-passed signal with the profile continued through f = 0 -- the kink there is what gives the Paul wavelet
+ *                  its 1/t^(m+1) tail; costs ~1.5e3 x the arithmetic's epsilon of rounding noise, so only where the accuracy
+ *                  target leaves room for it: fp64 at targets >= ~2e-12)
  *   "chunk_rows"   rows per two-pass chunk (intermediate = chunk_rows*nfft complex); 0 = default:
  *                  as many rows as fit 192 MiB, so that the intermediate stays in the Infinity Cache
  *   "narrow"       0 disables the band-limited single-pass path

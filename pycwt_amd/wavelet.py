@@ -439,7 +439,8 @@ class DeviceTransform:
 
 def cwt_device(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, precision=None, device=0):
     """`cwt` whose result stays on the GPU: returns a `DeviceTransform` (attributes sj, freqs, coi, fft,
-    fftfreqs as in `cwt`; methods W(), global_power(), scale_average(), icwt())."""
+    fftfreqs as in `cwt` -- read-only views of the cached grids; `fft`, the spectrum, is downloaded when first asked for
+    and must be asked for before `close()`; methods W(), global_power(), scale_average(), icwt())."""
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     n0 = len(signal)
