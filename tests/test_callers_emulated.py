@@ -225,12 +225,12 @@ def test_device_resident_xwt_and_wct_give_the_host_results(emulated, g):
 @pytest.mark.parametrize("surrogates,al", [("reference", (0.3, 0.5)), ("ar1", (0.6, 0.8))])
 def test_wct_significance_with_surrogates_made_on_the_device(emulated, tmp_path, monkeypatch, surrogates, al):
     """`rng="device"`: Philox surrogates instead of NumPy's.  Another generator, the same distributions: the 95 % levels of
-    250 device draws against 250 NumPy draws of the same problem agree within the Monte-Carlo error (the levels of two
+    40 device draws against 40 NumPy draws of the same problem agree within the Monte-Carlo error (the levels of two
     independent NumPy runs differ by as much: checked here too, as the yardstick), are reproducible per seed, follow
     np.random.seed when no seed is given, and cache under their own file name."""
     from pycwt_amd import wavelet
     monkeypatch.setattr(wavelet, "get_cache_dir", lambda: str(tmp_path) + "/")
-    kw = dict(dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=250, progress=False, wavelet="morlet", surrogates=surrogates, cache=False)
+    kw = dict(dt=1.0, dj=0.5, s0=2.0, J=6, mc_count=40, progress=False, wavelet="morlet", surrogates=surrogates, cache=False)
     np.random.seed(1)
     host_a = pycwt_amd.wct_significance(*al, **kw)
     np.random.seed(2)
@@ -245,9 +245,9 @@ def test_wct_significance_with_surrogates_made_on_the_device(emulated, tmp_path,
     np.testing.assert_array_equal(pycwt_amd.wct_significance(*al, rng="device", seed=11, **kw), dev_a)      # reproducible
     assert not np.array_equal(dev_a[ok], dev_b[ok])
     np.random.seed(5)
-    s1 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=20))
+    s1 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=6))
     np.random.seed(5)
-    s2 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=20))
+    s2 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=6))
     np.testing.assert_array_equal(s1, s2)
     pycwt_amd.wct_significance(*al, rng="device", seed=3, **dict(kw, mc_count=4, cache=True))
     assert len(list(tmp_path.glob("wct_sig_*_devrng.gz"))) == 1
