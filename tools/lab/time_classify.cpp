@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
       best = std::min(best, ms);
     }
     set_split(p);
-    printf("%-12s build_row_table %.3f ms  (poly %d ols %d aols %d wide %d)\n", c.name, best, p->rt->n_poly, p->rt->n_ols, p->rt->n_aols, p->rt->n_wide);
+    printf("%-12s build_row_table %.3f ms  (poly %d ols %d aols %d wide %d) planes %.1f MB in %zu chunks, bands %.1f MB\n", c.name, best, p->rt->n_poly, p->rt->n_ols, p->rt->n_aols, p->rt->n_wide, p->rt->poly_coef_elems * (c.prec == 64 ? 16.0 : 8.0) / 1e6, p->rt->poly_chunks.size(), p->rt->poly_band_elems * (c.prec == 64 ? 16.0 : 8.0) / 1e6);
   }
   return 0;
 }
