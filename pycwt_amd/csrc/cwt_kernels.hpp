@@ -46,8 +46,11 @@
 #ifndef CWT_LB_OLS_F32
 #define CWT_LB_OLS_F32 6      // 80 VGPRs -> three 512-thread workgroups per CU: overlap-save kernel -7 % (fp32 DOG / Paul)
 #endif
-#ifndef CWT_LB_OLS_F32_HALF
-#define CWT_LB_OLS_F32_HALF 6 // the same kernel on half-size tiles (256 threads)
+#ifndef CWT_LB_OLS_F32_HALF   // the same kernel on half-size tiles (256 threads).  With block pairs (CWT_PAIR_F32) the data alone
+#define CWT_LB_OLS_F32_HALF (CWT_PAIR_F32 ? 3 : 6)   // are 64 registers: 168 (3 waves per SIMD, no scratch) 2.02 us per row, 128
+#endif                                               // (45 spilled) 2.93, one block per workgroup at 80: 2.28
+#ifndef CWT_LB_AOLS_F32
+#define CWT_LB_AOLS_F32 (CWT_PAIR_F32 ? 4 : 6)       // k_aols_rows<float>: 106 registers as block pairs
 #endif
 #ifndef CWT_LB_OLS_F64_HALF
 #define CWT_LB_OLS_F64_HALF 4

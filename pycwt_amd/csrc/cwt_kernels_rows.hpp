@@ -225,6 +225,114 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
   }
 }
 
+// ---- complex64: TWO blocks of a row per workgroup -------------------------------------------------------------------
+// The block transforms are bound by the issue rate of the vector ALU (a 4096-point tile is ~1000 instructions per thread,
+// 2.4 us per row of 2^20 outputs against 1.0 for its bytes).  gfx950 issues packed fp32 instructions -- two results per slot --
+// so in complex64 a workgroup transforms blocks 2u and 2u + 1 of its row TOGETHER: every data register is a pairf (block 2u in
+// the low half, 2u + 1 in the high half), filter table, twiddles and addresses are shared, the exchange buffer holds 8-byte
+// elements.  The odd block out at the end of a row is transformed twice and stored once (nlim of the second half <= 0).
+// Which kernels: ols_pairs() / aols_pairs() in cwt_types.hpp (the host sizes the grids from the same functions);
+// -DCWT_PAIR_F32=0 keeps one block per workgroup everywhere (A/B).  [measured, fp32 DOG / Paul at N = 2^20: the instruction
+// count per block falls 1.8 x, the 4096-point rows gain 11 % (2.28 -> 2.02 us), the rows on the band-passed signal 10-20 %
+// (2.35-2.47 -> 1.94-2.14): these kernels are NOT bound by the issue rate alone]
+__device__ __forceinline__ pairf pair_of(float a, float b) { pairf v = {a, b}; return v; }
+
+template <int LOGP>
+__device__ __forceinline__ void ols_full_body2(const float2* __restrict__ xb0, const float2* __restrict__ xb1, const RowDesc& rd,
+                                               const float2* __restrict__ gt, const float2* __restrict__ tw_all,
+                                               float2* __restrict__ w0, float2* __restrict__ w1, int H, int nlim0, int nlim1,
+                                               pairf* lds) {
+  constexpr int P = 1 << LOGP, NT = P >> 4;
+  using F = ct::Fft<pairf, LOGP, 0, false>;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  pairf re[16], im[16];
+  float2 gv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {                          // all loads first, then the arithmetic
+    const int ks = signed_bin(f.j + e * NT, P);
+    const float2 a = ols_load<float>(xb0, rd, ks), b = ols_load<float>(xb1, rd, ks);
+    re[e] = pair_of(a.x, b.x);
+    im[e] = ks < 0 ? pair_of(-a.y, -b.y) : pair_of(a.y, b.y);
+    gv[e] = gt[f.j + e * NT];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const pairf x = re[e], y = im[e];
+    re[e] = x * gv[e].x - y * gv[e].y;
+    im[e] = x * gv[e].y + y * gv[e].x;
+  }
+  f.run(re, im, lds, tw_all + (P - 2));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int nl = f.j + e * NT - H;
+    if (nl >= 0 && nl < nlim0) store_w<float>(w0 + nl, re[e][0], im[e][0]);
+    if (nl >= 0 && nl < nlim1) store_w<float>(w1 + nl, re[e][1], im[e][1]);
+  }
+}
+
+template <int LOGK, int LOGP>
+__device__ __forceinline__ void ols_band_body2(const float2* __restrict__ xb0, const float2* __restrict__ xb1, const RowDesc& rd,
+                                               const float2* __restrict__ gt, const float2* __restrict__ tw_all,
+                                               const TwN<float>& twn, int logN, float2* __restrict__ w0, float2* __restrict__ w1,
+                                               int H, int nlim0, int nlim1, pairf* lds, int logx, unsigned g) {
+  constexpr int LOGTB = LOGP - LOGK, K = 1 << LOGK, NT = K >> 4, BD = 1 << (LOGP - 4);
+  using F = ct::Fft<pairf, LOGK, LOGTB, true, (LOGTB <= CWT_OLS_PAD_LOGTB)>;
+  F f;
+  f.t = threadIdx.x & ((1 << LOGTB) - 1);
+  f.j = threadIdx.x >> LOGTB;
+  const unsigned r = (g << LOGTB) + unsigned(f.t);
+  pairf* ytile = lds;                                     // the filtered band of both blocks: (re, im) pairs, 16 bytes per bin
+  constexpr int NQ = K > BD ? K / BD : 1;
+  float2 ya[NQ], yb[NQ], gv[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = int(threadIdx.x) + i * BD;
+    if (q < K) {
+      const int ks = rd.k_lo + ((q - rd.k_lo) & (K - 1));
+      ya[i] = ols_load<float>(xb0, rd, ks);
+      yb[i] = ols_load<float>(xb1, rd, ks);
+      gv[i] = gt[q];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = int(threadIdx.x) + i * BD;
+    if (q < K) {
+      const int ks = rd.k_lo + ((q - rd.k_lo) & (K - 1));
+      const pairf x = pair_of(ya[i].x, yb[i].x), y = ks < 0 ? pair_of(-ya[i].y, -yb[i].y) : pair_of(ya[i].y, yb[i].y);
+      ytile[2 * q] = x * gv[i].x - y * gv[i].y;
+      ytile[2 * q + 1] = x * gv[i].y + y * gv[i].x;
+    }
+  }
+  __syncthreads();
+  const int sh = logN - LOGP - logx;
+  const unsigned pm = (1u << (LOGP + logx)) - 1u;
+  const float2 step = twn(((unsigned(NT) * r) & pm) << sh);
+  const float2 rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
+  const int c0 = ((0 - rd.k_lo) & (K - 1)) >> (LOGK - 4);
+  const int ew = 16 - c0;
+  float2 cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
+  pairf re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const pairf yx = ytile[2 * (f.j + e * NT)], yy = ytile[2 * (f.j + e * NT) + 1];
+    re[e] = yx * cur.x - yy * cur.y;
+    im[e] = yx * cur.y + yy * cur.x;
+    if (e < 15) cur = cmul<float>(cur, step);
+    if (e + 1 == ew) cur = cmul<float>(cur, rhoc);                     // uniform branch
+  }
+  __syncthreads();                                       // the band tile aliases the exchange buffer
+  f.run(re, im, lds, tw_all + (K - 2));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
+    if (nl >= 0 && nl < nlim0) store_w<float>(w0 + nl, re[e][0], im[e][0]);
+    if (nl >= 0 && nl < nlim1) store_w<float>(w1 + nl, re[e][1], im[e][1]);
+  }
+}
+
 // All overlap-save rows of a transform in one launch: 1-D grid, class c owns workgroups [wg_first, next wg_first);
 // inside a class the 8 XCDs (workgroup id & 7) take every 8th block and walk all rows of a block back to back, so that
 // a block spectrum is fetched into one L2 once and read there by every row.
@@ -249,9 +357,12 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
   // (signal, block) pairs vb = signal * nblocks + block: XCD (workgroup id & 7) takes every 8th pair and walks the
   // nrs rows of that signal's class back to back; the class's rows are stored scale by scale, nsig signals each
   const unsigned seq = local >> (3 + logx), nsig = unsigned(oc.nsig), nrs = unsigned(oc.nrows) / nsig;
+  // unit = one block, or (complex64) the blocks 2u, 2u + 1
+  constexpr bool PAIR = ols_pairs(sizeof(T), LOGP);
+  const unsigned nunits = PAIR ? (unsigned(oc.nblocks) + 1u) >> 1 : unsigned(oc.nblocks);
   const unsigned vb = (seq / nrs) * 8u + (local & 7u);
-  if (vb >= unsigned(oc.nblocks) * nsig) return;
-  const unsigned sig = vb / unsigned(oc.nblocks), blk = vb - sig * unsigned(oc.nblocks);
+  if (vb >= nunits * nsig) return;
+  const unsigned sig = vb / nunits, unit = vb - sig * nunits, blk = PAIR ? 2u * unit : unit;
   const RowDesc rd = rows[oc.row_first + int((seq % nrs) * nsig + sig)];
   const int H = oc.halo, L = (P << logx) - 2 * H;
   const cplx<T>* xb = xs + rd.spec_off + oc.xs_off + long(blk) * ((P << logx) / 2 + 8);   // spec_off: the row's signal (batch)
@@ -260,6 +371,25 @@ k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const
   const int nlim = left < L ? int(left) : L;
   cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
   const cplx<T>* gt = gtab + rd.tab_off;
+  if constexpr (PAIR) {
+    const bool two = blk + 1u < unsigned(oc.nblocks);
+    const float2* xb1 = two ? xb + ((P << logx) / 2 + 8) : xb;
+    const long left1 = left - L;
+    const int nlim1 = !two ? 0 : left1 < L ? int(left1) : L;
+    pairf* lds2 = reinterpret_cast<pairf*>(lds_raw);
+#define CWT_OLS_CASE2(LK)                                                                                                    \
+  case LK:                                                                                                                    \
+    if constexpr (LK < LOGP) ols_band_body2<LK, LOGP>(xb, xb1, rd, gt, tw_all, twn, logN, wout, wout + L, H, nlim, nlim1, lds2, logx, g); \
+    else ols_full_body2<LOGP>(xb, xb1, rd, gt, tw_all, wout, wout + L, H, nlim, nlim1, lds2);                                  \
+    break;
+    switch (rd.logK) {
+      CWT_OLS_CASE2(4) CWT_OLS_CASE2(5) CWT_OLS_CASE2(6) CWT_OLS_CASE2(7) CWT_OLS_CASE2(8) CWT_OLS_CASE2(9)
+      CWT_OLS_CASE2(10) CWT_OLS_CASE2(11) CWT_OLS_CASE2(12) CWT_OLS_CASE2(13)
+      default: ols_full_body2<LOGP>(xb, xb1, rd, gt, tw_all, wout, wout + L, H, nlim, nlim1, lds2); break;
+    }
+#undef CWT_OLS_CASE2
+    return;
+  }
 #define CWT_OLS_CASE(LK)                                                                            \
   case LK:                                                                                           \
     if constexpr (LK < LOGP) ols_band_body<T, LK, LOGP>(xb, rd, gt, tw_all, twn, logN, wout, H, nlim, lds, logx, g); \
@@ -365,17 +495,18 @@ k_aols_fwd(const cplx<T>* __restrict__ xm, int logN, int halo, const cplx<T>* __
 // blockIdx.y = signal of a batch: its rows at rows + y g.nrows, its block spectra at xs + y nblocks (P + 8); xhat = the
 // spectra of the batch (the Nyquist bin of a row's signal at xhat[rd.spec_off + N / 2], two-sided filters only).
 template <typename T, int LOGP>
-__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64)
-                                                                : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
+__global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12 ? CWT_LB_OLS_F64_HALF : CWT_LB_OLS_F64) : CWT_LB_AOLS_F32))
 k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const T* __restrict__ gtab,
             const cplx<T>* __restrict__ tw_all, AolsGeom g, const cplx<T>* __restrict__ xhat, long nyq, cplx<T>* __restrict__ W,
             long ldw, long ncols) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int P = 1 << LOGP, NT = P >> 4;
+  constexpr bool PAIR = aols_pairs(sizeof(T));                 // complex64: blocks 2u, 2u + 1 in one workgroup (see ols_band_body2)
   using F = ct::Fft<T, LOGP, 0, false>;
   const unsigned seq = blockIdx.x >> 3;
-  const unsigned blk = (seq / unsigned(g.nrows)) * 8u + (blockIdx.x & 7u);
+  const unsigned unit = (seq / unsigned(g.nrows)) * 8u + (blockIdx.x & 7u);
+  const unsigned blk = PAIR ? 2u * unit : unit;
   if (blk >= unsigned(g.nblocks)) return;
   const RowDesc rd = rows[blockIdx.y * unsigned(g.nrows) + seq % unsigned(g.nrows)];
   const int H = g.halo, L = P - 2 * H;
@@ -384,6 +515,49 @@ k_aols_rows(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, co
   const long col0 = long(blk) * L, left = ncols - col0;
   const int nlim = left < L ? int(left) : L;
   cplx<T>* wout = W + long(rd.out_row) * ldw + col0;
+  if constexpr (PAIR) {
+    using F2 = ct::Fft<pairf, LOGP, 0, false>;
+    const bool two = blk + 1u < unsigned(g.nblocks);
+    const float2* xb1 = two ? xb + (P + 8) : xb;
+    const long left1 = left - L;
+    const int nlim1 = !two ? 0 : left1 < L ? int(left1) : L;
+    float2* wout1 = wout + L;
+    F2 f;
+    f.t = 0;
+    f.j = threadIdx.x;
+    pairf re[16], im[16];
+    float gv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {                        // all loads first, then the arithmetic
+      const float2 a = xb[f.j + e * NT], b = xb1[f.j + e * NT];
+      re[e] = pair_of(a.x, b.x); im[e] = pair_of(a.y, b.y);
+      gv[e] = gt[f.j + e * NT];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { re[e] *= gv[e]; im[e] *= gv[e]; }
+    f.run(re, im, reinterpret_cast<pairf*>(lds_raw), tw_all + (P - 2));
+    if (rd.nterms == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = f.j + e * NT - H;
+        if (nl >= 0 && nl < nlim) store_w<float>(wout + nl, re[e][0], im[e][0]);
+        if (nl >= 0 && nl < nlim1) store_w<float>(wout1 + nl, re[e][1], im[e][1]);
+      }
+    } else {                                              // two-sided real filter of a real signal (see above)
+      const float2 xn = xhat[rd.spec_off + nyq];
+      const float nr = float(rd.nyq_re) * xn.x - float(rd.nyq_im) * xn.y, ni = float(rd.nyq_re) * xn.y + float(rd.nyq_im) * xn.x;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = f.j + e * NT - H;
+        const pairf v = rd.nterms == 2 ? 2.0f * re[e] : -2.0f * im[e];
+        const float sg = ((col0 + nl) & 1) ? -1.0f : 1.0f;            // (-1)^n
+        const float sg1 = (L & 1) ? -sg : sg;
+        if (nl >= 0 && nl < nlim) store_w<float>(wout + nl, v[0] + sg * nr, sg * ni);
+        if (nl >= 0 && nl < nlim1) store_w<float>(wout1 + nl, v[1] + sg1 * nr, sg1 * ni);
+      }
+    }
+    return;
+  }
   F f;
   f.t = 0;
   f.j = threadIdx.x;

@@ -70,6 +70,15 @@ struct AolsGeom {
 };
 
 // ---- band-limited rows in polynomial form ----
+// complex64: the overlap-save kernels on 4096-point tiles (k_ols_ct<float, 12>, k_aols_rows<float, .>) transform two blocks
+// of a row per workgroup in packed fp32 arithmetic (cwt_kernels_rows.hpp, ols_band_body2); the host sizes their grids in block
+// PAIRS.  0 = one block per workgroup everywhere.  Not the 8192-point tiles of k_ols_ct: 512 threads x 128+ registers leave one
+// workgroup per CU (measured 3.3 -> 4.0-4.2 us per row).
+#ifndef CWT_PAIR_F32
+#define CWT_PAIR_F32 1
+#endif
+constexpr bool ols_pairs(int real_bytes, int logp) { return CWT_PAIR_F32 != 0 && real_bytes == 4 && logp == 12; }
+constexpr bool aols_pairs(int real_bytes) { return CWT_PAIR_F32 != 0 && real_bytes == 4; }
 constexpr int POLY_MAX_CLASSES = 8;       // K' = 2^8 ... 2^14 + one spare
 constexpr int POLY_LOGP = 14;             // largest K' = points per workgroup of the largest k_poly_coef tile (1024 threads)
 constexpr int POLY_MAX_DEGREE = 24;

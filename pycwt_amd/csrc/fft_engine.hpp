@@ -33,6 +33,16 @@ template <> struct C2<double> { using type = double2; };
 template <> struct C2<float> { using type = float2; };
 template <typename T> using cplx = typename C2<T>::type;
 
+// Two independent transforms in the lanes of one thread: a pair of floats that the compiler keeps in an aligned register pair
+// and drives with gfx950's packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two results per issue
+// slot).  The engine below is generic over the DATA type T (float, double or pairf); twiddles and butterfly constants are
+// scalars of sc_t<T> and broadcast to both halves (op_sel: no extra instruction).  An LDS element of pairf is 8 bytes, so
+// the layouts behave as they do for double.
+typedef float pairf __attribute__((vector_size(8)));
+template <typename T> struct ScalarOf { using type = T; };
+template <> struct ScalarOf<pairf> { using type = float; };
+template <typename T> using sc_t = typename ScalarOf<T>::type;
+
 template <typename T>
 __host__ __device__ __forceinline__ cplx<T> mk(T x, T y) {
   cplx<T> c;
@@ -116,7 +126,8 @@ template <typename T> struct K16 {
 // multiply (r,i) by e^{+2*pi*i*Q/16} for the Q that occur in the 4x4 split
 template <typename T, int Q>
 __device__ __forceinline__ void rot16(T& r, T& i) {
-  constexpr T C = K16<T>::C, S = K16<T>::S, H = K16<T>::H;
+  using R = sc_t<T>;
+  constexpr R C = K16<R>::C, S = K16<R>::S, H = K16<R>::H;
   T x = r, y = i;
   if constexpr (Q == 0) { return; }
   else if constexpr (Q == 1) { r = x * C - y * S; i = x * S + y * C; }
@@ -185,16 +196,16 @@ __device__ __forceinline__ void bfly_small(T (&re)[R], T (&im)[R]) {
 // depth 4 instead of 15 at the same 14 complex multiplications) measured +1 % in fp64 and +17 % in fp32 (its 15 live
 // powers cost registers: spills at the 80-VGPR budget of the fp32 kernels); removing the chain altogether (timing only)
 // is worth -2.5 % of the fp64 step.
-template <typename T, int R>
-__device__ __forceinline__ void twiddle_chain(T (&re)[R], T (&im)[R], T wr, T wi) {
-  T pr = wr, pi = wi;
+template <typename T, int R, typename S>
+__device__ __forceinline__ void twiddle_chain(T (&re)[R], T (&im)[R], S wr, S wi) {
+  S pr = wr, pi = wi;
 #pragma unroll
   for (int m = 1; m < R; ++m) {
     const T x = re[m], y = im[m];
     re[m] = x * pr - y * pi;
     im[m] = x * pi + y * pr;
     if (m + 1 < R) {
-      const T nr = pr * wr - pi * wi;
+      const S nr = pr * wr - pi * wi;
       pi = pr * wi + pi * wr;
       pr = nr;
     }
@@ -217,7 +228,7 @@ __device__ __forceinline__ void exchange_plane(T (&v)[16], T* lds, const Geo<T, 
 // last stage when log2 L is not a multiple of 4: radix R = 2^rem, 16/R butterflies per thread
 template <typename T, int R>
 __device__ __forceinline__ void partial_stage(T (&re)[16], T (&im)[16], int j, int logL, int logNs,
-                                              const cplx<T>* __restrict__ tw) {
+                                              const cplx<sc_t<T>>* __restrict__ tw) {
   constexpr int NB = 16 / R;
   constexpr int LOGR = (R == 2) ? 1 : (R == 4) ? 2 : 3;
   const int logNT = logL - 4;
@@ -225,7 +236,7 @@ __device__ __forceinline__ void partial_stage(T (&re)[16], T (&im)[16], int j, i
   for (int u = 0; u < NB; ++u) {
     const int jj = j + (u << logNT);
     const int k = jj & ((1 << logNs) - 1);
-    const cplx<T> w = stage_tw<T>(tw, k << (logL - logNs - LOGR));
+    const cplx<sc_t<T>> w = stage_tw<sc_t<T>>(tw, k << (logL - logNs - LOGR));
     T lr[R], li[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) { lr[i] = re[u + i * NB]; li[i] = im[u + i * NB]; }
@@ -347,11 +358,11 @@ struct Fft {
 
   template <int S>
   __device__ __forceinline__ void full_stage(T (&re)[16], T (&im)[16], T* lds,
-                                             const cplx<T>* __restrict__ tw, int rphys) const {
+                                             const cplx<sc_t<T>>* __restrict__ tw, int rphys) const {
     constexpr int LOGNS = 4 * S;
     const int k = j & ((1 << LOGNS) - 1);
     if constexpr (S > 0) {
-      const cplx<T> w = stage_tw<T>(tw, k << (LOGL - LOGNS - 4));
+      const cplx<sc_t<T>> w = stage_tw<sc_t<T>>(tw, k << (LOGL - LOGNS - 4));
       twiddle_chain<T, 16>(re, im, w.x, w.y);
     }
     bfly16<T>(re, im);
@@ -363,7 +374,7 @@ struct Fft {
 
   // in: slot e = x[j + e*NT]; out: slot e = X[j + e*NT].  lds: LDS_ELEMS reals.
   __device__ __forceinline__ void run(T (&re)[16], T (&im)[16], T* lds,
-                                      const cplx<T>* __restrict__ tw) const {
+                                      const cplx<sc_t<T>>* __restrict__ tw) const {
     const int rphys = phys(j);
     full_stage<0>(re, im, lds, tw, rphys);
     if constexpr (NFULL >= 2) full_stage<1>(re, im, lds, tw, rphys);

@@ -365,7 +365,8 @@ int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols
   const auto& G = rt->ols_grp[g];
   static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP>), true);
   (void)once;
-  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  // (complex64: two blocks per workgroup, 8-byte exchange elements)
+  const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * (ols_pairs(sizeof(T), LOGP) ? sizeof(pairf) : sizeof(T));
   return timed_launch(p, g == 0 ? KC_OLS_SMALL : KC_OLS, [&] {
     hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(G.wgs)), dim3(1 << (LOGP - 4)), lds, st,
                        static_cast<const cplx<T>*>(p->xs), rt->rows_dev + rt->ols_first + G.row_first,
@@ -412,6 +413,7 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   static const bool once = (allow_big_lds(&k_aols_fwd<T, LOGP>), allow_big_lds(&k_aols_rows<T, LOGP>), true);
   (void)once;
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * sizeof(T);
+  const size_t lds_rows = aols_pairs(sizeof(T)) ? 2 * lds : lds;      // complex64 rows: two blocks per workgroup
   for (int b0 = 0; b0 < nb; b0 += chunk) {
     const int cnt = std::min(chunk, nb - b0);
     bool ok = true;
@@ -428,7 +430,7 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
     if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
-      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st,
+      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds_rows, st,
                          static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
                          static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
                          static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W, long(ldw), long(ncols));
@@ -455,7 +457,8 @@ int launch_aols_second(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ld
                        static_cast<cplx<T>*>(p->xsa));
   }, st);
   if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
-    hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols2_wgs), 1u), dim3(1 << (LOGP - 4)), lds, st,
+    hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols2_wgs), 1u), dim3(1 << (LOGP - 4)),
+                       aols_pairs(sizeof(T)) ? 2 * lds : lds, st,
                        static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols2_first, static_cast<const T*>(rt->agt_dev),
                        static_cast<const cplx<T>*>(p->tw_all), g, static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W,
                        long(ldw), long(ncols));

@@ -989,7 +989,9 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           k.xs_off = xs;
           // the 8 XCDs share the (signal, block) pairs: nblocks alone can be as few as 17 (N = 2^16), which would leave
           // one XCD with 3 blocks and seven with 2 + an idle pass (measured: +40 % on that kernel)
-          wg += ((long(k.nblocks) * ols_nbatch + 7) / 8) * 8 * (k.nrows / ols_nbatch) * G;
+          // (complex64: a workgroup takes two blocks of a row, CWT_PAIR_F32)
+          const long nunits = ols_pairs(p->prec / 8, grp.logp) ? (k.nblocks + 1) / 2 : k.nblocks;
+          wg += ((nunits * ols_nbatch + 7) / 8) * 8 * (k.nrows / ols_nbatch) * G;
           blk += k.nblocks;
           xs += long(k.nblocks) * stride;
           lo_d = hi_d;
@@ -1033,7 +1035,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     p->rt->table.insert(p->rt->table.end(), aols_rows.begin(), aols_rows.end());
     p->rt->aols_logp = aols_logp;
     p->rt->aols_geom = ag;
-    p->rt->aols_wgs = long((ag.nblocks + 7) / 8) * 8 * ag.nrows;
+    const bool pair32 = aols_pairs(p->prec / 8);                // a workgroup of k_aols_rows takes two blocks of a row
+    p->rt->aols_wgs = long(((pair32 ? (ag.nblocks + 1) / 2 : ag.nblocks) + 7) / 8) * 8 * ag.nrows;
     p->rt->aols_gt_elems = long(ag.nrows) << aols_logp;
     p->rt->aols_nbatch = aols_nbatch;
     // second class (Paul rows continued through f = 0 on 8192-point tiles): right behind the first in the table
@@ -1043,7 +1046,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     if (!aols2_rows.empty()) {
       p->rt->table.insert(p->rt->table.end(), aols2_rows.begin(), aols2_rows.end());
       p->rt->aols2_geom = ag2;
-      p->rt->aols2_wgs = long((ag2.nblocks + 7) / 8) * 8 * ag2.nrows;
+      p->rt->aols2_wgs = long(((pair32 ? (ag2.nblocks + 1) / 2 : ag2.nblocks) + 7) / 8) * 8 * ag2.nrows;
       p->rt->aols_gt_elems += long(ag2.nrows) << 13;
     }
     RowDesc m{};                                          // (zero-initialised: no Nyquist term) the mask as a row: profile 1 (DOG m = 0 at a = 0) on [k_s, N/2)

@@ -268,3 +268,24 @@ def test_paul_rows_continued_through_zero_frequency(emu_library, monkeypatch):
     for prec, tol in ((64, 1e-16), (32, 3e-5)):
         _, s2, c2 = transform(emu_library, N, x, orc.PAUL, 4, sj, prec, dict(opts, tolerance=tol))
         assert not any(c == "aols/P8192" for c in c2), (prec, s2)
+
+
+@pytest.mark.parametrize("kind,param", [(orc.DOG, 2), (orc.PAUL, 4), (orc.MORLET, 6)])
+def test_complex64_overlap_save_rows_as_block_pairs(emu_library, kind, param):
+    """complex64: a workgroup of k_ols_ct<float, 12> / k_aols_rows<float> transforms blocks 2u and 2u + 1 of its row in the two
+    halves of packed registers.  Signal lengths one block apart, so that rows end on a full pair AND on the odd block out;
+    every row of both forms against the oracle."""
+    N = 1 << 16
+    m = orc.Mother(kind, param)
+    seen = set()
+    for n0 in (N, N - 2900, N - 5800, N - 8700 - 1):
+        x = np.random.default_rng(n0).standard_normal(n0)
+        sj = grid(n0, 1.0, m, 64)
+        W, split, classes = transform(emu_library, N, x, kind, param, sj, 32, {"ols_min_logn": 15, "poly": 0})
+        mine = [i for i, c in enumerate(classes) if c.startswith(("ols", "aols"))]
+        assert split["ols"] >= 4 and split["aols"] >= 3, split
+        seen.update(classes[i].split("/")[0] for i in mine)
+        ref = orc.cwt_rows(x, 1.0, sj[mine], m, N=N)[:, :n0]
+        per_row, _ = row_errors(W[mine], ref)
+        assert per_row.max() < TOL[32], (n0, per_row.argmax(), per_row.max(), classes[mine[per_row.argmax()]])
+    assert {"ols", "aols"} <= seen
