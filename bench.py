@@ -823,6 +823,9 @@ def main():
                          "--force-dist broadcast if given; `value` is then what G such ranks would deliver together")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="diagnostic: this many signals in flight (step i on plan / stream / W buffer i mod P); the headline is 1")
+    ap.add_argument("--dummy-streams", type=int, default=0,
+                    help="diagnostic: create this many idle HIP streams before the plan (the runtime maps streams to a few hardware "
+                         "queues; a plan whose own streams share one loses its overlap)")
     ap.add_argument("--no-prime", dest="prime", action="store_false",
                     help="do not bring the device to its sustained clocks before the W warm-up steps (then `value` is what "
                          "`from_idle` reports otherwise)")
@@ -855,6 +858,11 @@ def main():
 
     rt = Runtime(args)
     world, rank = rt.world, rt.rank
+    dummies = [rt.torch.cuda.Stream(device=rt.dev) for _ in range(args.dummy_streams)] if not args.emulate else []
+    for st in dummies:                         # (a stream gets its hardware queue at first use)
+        with rt.torch.cuda.stream(st):
+            rt.torch.zeros(1, device=rt.dev)
+    rt.sync()
     opts = {k: int(v) for k, v in (o.split("=") for o in args.opt)}
     kind, param, prec, label = CONFIGS[args.config]
     N = 1 << args.logn

@@ -118,6 +118,10 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "host_direct"  0 = cwt_execute_host stages transforms that fit one workgroup per row through device buffers and copy
  *                  operations like the longer ones (default 1: their kernels read the signal from and write W into
  *                  page-locked host memory themselves)
+ *   "queue_probe"  0 = take the side streams as the runtime made them (default 1: before its first long transform on a
+ *                  caller's stream the plan measures -- two one-thread kernels, ~0.3 ms once -- whether its four streams
+ *                  sit on four hardware queues, and replaces side streams that share one: streams created earlier in the
+ *                  process, e.g. by other plans or the framework, otherwise cost 2-6 % of the step)
  *   "graph"        1 = repeated cwt_transform calls with the same buffers and scale grid are captured into a HIP graph
  *                  and replayed (default 0: measured +-0.5 % on the step, the chain is latency bound, not launch bound)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)

@@ -46,6 +46,7 @@ int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, 
 int transform_rows_common(cwt_plan* p, const void* xhat_dev, const void* x_dev, int64_t n0, int mother, double param,
                           double dt, const double* scales, int nrows, void* W_dev, int64_t ldw, int64_t ncols) {
   int rc = prepare_rows_table(p, x_dev != nullptr, mother, param, dt, scales, nrows, ldw, ncols);
+  if (!rc && p->logN >= 18 && !p->profile) rc = ensure_distinct_queues(p);
   if (rc) return rc;
   const Mother mo = mother_of(mother, param);
   return p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
@@ -115,6 +116,79 @@ double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double n
 }  // namespace
 
 // =============================================================================================
+// ---- hardware queues ---------------------------------------------------------------------------------------------------
+// A long transform runs on four streams (the caller's + three side streams).  The runtime multiplexes ALL streams of the
+// process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in the order they were created; two of the plan's
+// streams that land on ONE queue execute in submission order and the overlap the schedule was built for is gone [measured:
+// fp32 Paul 0.600 -> 0.618 / 0.637 ms with one / two idle streams created before the plan, fp64 Morlet 0.935 -> 0.952;
+// the config-3 blocks of a default bench run, whose plans come after a dozen others, 6-10 % slower than alone].  HIP has no
+// query for a stream's queue, so the plan MEASURES it: a one-thread kernel on stream a waits (bounded: 200 us) for a flag that
+// a one-thread kernel on stream b sets; submitted in that order, b can only get through if it sits on another queue.  A side
+// stream that shares a queue with the caller's stream or with an earlier side stream is parked (kept alive, idle, so that the
+// runtime's least-used-queue choice moves on) and replaced.  Once per plan and caller's stream, ~0.3 ms; only for transforms
+// long enough to use the side streams.  Option "queue_probe" = 0 turns it off.
+#if defined(CWT_HIP_EMULATED)
+int cwtd::ensure_distinct_queues(cwt_plan*) { return CWT_OK; }     // (the CPU stand-in of the tests runs kernels in launch order)
+#else
+__global__ void k_queue_probe_wait(int* flag, int* seen, long long ticks) {
+  const long long t0 = wall_clock64();                              // 100 MHz
+  int s = 0;
+  do {
+    s = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (!s) __builtin_amdgcn_s_sleep(16);
+  } while (!s && wall_clock64() - t0 < ticks);
+  *seen = s;
+}
+__global__ void k_queue_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// true: kernels of a and b run side by side (different hardware queues)
+static int queues_differ(cwt_plan* p, hipStream_t a, hipStream_t b, bool* differ) {
+  HIPCHECK(hipMemsetAsync(p->probe_dev, 0, 2 * sizeof(int), a));
+  HIPCHECK(hipEventRecord(p->ev_probe, a));
+  HIPCHECK(hipStreamWaitEvent(b, p->ev_probe, 0));
+  hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(1), 0, a, p->probe_dev, p->probe_dev + 1, 20000LL);
+  hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, p->probe_dev);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(a));
+  HIPCHECK(hipStreamSynchronize(b));
+  int h[2] = {0, 0};
+  HIPCHECK(hipMemcpy(h, p->probe_dev, sizeof(h), hipMemcpyDeviceToHost));
+  *differ = h[1] != 0;
+  return CWT_OK;
+}
+
+int cwtd::ensure_distinct_queues(cwt_plan* p) {
+  if (!p->queue_probe || (p->queues_probed && p->probed_main == p->stream)) return CWT_OK;
+  if (!p->probe_dev && hipMalloc(reinterpret_cast<void**>(&p->probe_dev), 2 * sizeof(int)) != hipSuccess)
+    return fail(CWT_ENOMEM, "device allocation failed");
+  if (!p->ev_probe) HIPCHECK(hipEventCreateWithFlags(&p->ev_probe, hipEventDisableTiming));
+  static const bool verbose = std::getenv("CWT_QUEUE_PROBE_VERBOSE") != nullptr;
+  hipStream_t* mine[3] = {&p->side[1], &p->side[0], &p->side2};     // by the work they carry: overlap-save chain first
+  hipStream_t fixed[4] = {p->stream, nullptr, nullptr, nullptr};
+  for (int i = 0; i < 3; ++i) {
+    for (int attempt = 0;; ++attempt) {
+      bool ok = true;
+      for (int j = 0; j <= i && ok; ++j) {
+        const int rc = queues_differ(p, fixed[j], *mine[i], &ok);
+        if (rc) return rc;
+      }
+      if (ok || attempt == 8) {
+        if (verbose) std::fprintf(stderr, "[cwt] side stream %d: %s after %d replacement(s)\n", i, ok ? "own hardware queue" : "still shares a queue", attempt);
+        break;
+      }
+      p->spacers.push_back(*mine[i]);                               // idle from here on; destroyed with the plan
+      HIPCHECK(create_side_stream(mine[i]));
+      ++p->queue_collisions;
+    }
+    fixed[i + 1] = *mine[i];
+  }
+  p->queues_probed = true;
+  p->probed_main = p->stream;
+  return CWT_OK;
+}
+#endif
+
+
 extern "C" {
 
 const char* cwt_backend(void) { return CWT_BACKEND_NAME; }
@@ -196,6 +270,9 @@ int cwt_plan_destroy(cwt_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_ols) (void)hipEventDestroy(p->ev_ols);
   if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
+  for (hipStream_t sp : p->spacers) (void)hipStreamDestroy(sp);
+  if (p->ev_probe) (void)hipEventDestroy(p->ev_probe);
+  if (p->probe_dev) (void)hipFree(p->probe_dev);
   if (p->ev_big) (void)hipEventDestroy(p->ev_big);
   for (auto& g : p->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -264,6 +341,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "aols_zc") p->aols_zc = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
+  else if (k == "queue_probe") { p->queue_probe = value != 0; }
   else if (k == "poly_chunk_mb") { if (value < 0 || value > 4096) return fail(CWT_EINVAL, "poly_chunk_mb in [0, 4096] (0 = one chunk)"); p->poly_chunk_mb = int(value); }
   else if (k == "poly_max_logk") { if (value < 8 || value > 14) return fail(CWT_EINVAL, "poly_max_logk in [8, 14]"); p->poly_max_logk = int(value); }
   else if (k == "poly_min_logn") { if (value < 14 || value > 24) return fail(CWT_EINVAL, "poly_min_logn in [14, 24]"); p->poly_min_logn = int(value); }
@@ -432,6 +510,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
   if (n0 < 1 || n0 > p->N) return fail(CWT_EINVAL, "n0 must be in [1, nfft]");
   HIPCHECK(hipSetDevice(p->device));
   int rc = prepare_rows_table(p, true, mother, param, dt, scales, nrows, ldw, ncols);
+  if (!rc && p->logN >= 18 && !p->profile) rc = ensure_distinct_queues(p);     // (transforms that use the side streams)
   if (rc) return rc;
   // the caller does not want the spectrum: computed (into plan scratch) only if some row needs it
   const bool only_ols = !xhat_dev && p->rt->n_ols == nrows;      // every row is an overlap-save row on the real signal

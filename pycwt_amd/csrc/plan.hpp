@@ -221,6 +221,15 @@ struct cwt_plan {
   hipStream_t side[2] = {nullptr, nullptr};       // side streams of the two-pass pipeline
   hipEvent_t ev_ols = nullptr;
   hipStream_t side2 = nullptr;       // third side stream: the multi-term band-limited kernels beside the one-term kernel
+  // Hardware queues (ensure_distinct_queues, abi.hip): the runtime multiplexes streams onto a few hardware queues (4 by
+  // default) in creation order; two of the plan's four streams on ONE queue run in submission order and lose their overlap
+  int queue_probe = 1;               // option "queue_probe"
+  bool queues_probed = false;
+  hipStream_t probed_main = nullptr; // the caller's stream the side streams were checked against
+  std::vector<hipStream_t> spacers;  // streams that collided: kept (idle) until the plan goes, so that their replacements land elsewhere
+  int* probe_dev = nullptr;          // flag + result of the probe kernels
+  hipEvent_t ev_probe = nullptr;
+  int queue_collisions = 0;          // streams replaced so far (cwt_plan_get_option "queue_collisions")
   hipEvent_t ev_big = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};
 
@@ -260,6 +269,7 @@ int check_geometry(const cwt_plan* p);
 int ensure_z(cwt_plan* p, int rows);
 int grow(void** buf, size_t* have, size_t need, hipStream_t s);
 int copy_d2h(cwt_plan* p, void* dst_host, const void* src_dev, size_t bytes);
+int ensure_distinct_queues(cwt_plan* p);          // abi.hip: the plan's four streams on four hardware queues
 hipError_t create_side_stream(hipStream_t* s);
 bool select_table(cwt_plan* p, const std::vector<double>& key);
 int upload_row_table(cwt_plan* p, const std::vector<double>& key);

@@ -9,6 +9,7 @@
 // a GPU.  It is never built into, loaded by, or reachable from the product
 // library (pycwt_amd/libcwt_hip.so); the product has no CPU path.
 #pragma once
+#define CWT_HIP_EMULATED 1     // lets the product sources skip what only makes sense on a device (hardware-queue probe)
 #include <ucontext.h>
 
 #include <atomic>

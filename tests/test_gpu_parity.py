@@ -990,6 +990,37 @@ def test_stream_placement_of_the_signal_path_keeps_every_bit(hip_library):
             assert np.array_equal(W, base), opts
 
 
+def test_replaced_side_streams_keep_every_bit(hip_library):
+    """The plan checks that its four streams sit on four hardware queues and replaces side streams that share one (streams
+    made earlier in the process shift the runtime's assignment).  Streams are only WHERE work is queued: with one, two and
+    three older streams in the way -- every assignment of the runtime's round -- W keeps the bits of a plan that takes its
+    streams as they come."""
+    import torch
+    N = 1 << 20
+    x = np.random.default_rng(79).standard_normal(N)
+    sj = grid(N, 1.0, orc.Mother(orc.MORLET, 6), 256)[:128:2]
+    older, base = [], None
+    for probe in (0, 1, 1, 1):
+        plan = _hip.Plan(N, 64, max_rows=64, options={"tolerance": 1e-9, "queue_probe": probe})
+        xd, xh, Wd = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 16), _hip.DeviceBuffer(len(sj) * N * 16)
+        xd.upload(plan, x)
+        for _ in range(3):
+            plan.transform(xd.ptr, N, orc.MORLET, 6.0, 1.0, sj, xh.ptr, Wd.ptr, N, N)
+        W = Wd.download(plan, (len(sj), N), np.complex128)
+        for b in (xd, xh, Wd):
+            b.free()
+        plan.close()
+        if base is None:
+            base = W
+        else:
+            assert np.array_equal(W, base), len(older)
+        st = torch.cuda.Stream()                          # one more stream in the way of the next plan's
+        with torch.cuda.stream(st):
+            torch.zeros(1, device="cuda")
+        torch.cuda.synchronize()
+        older.append(st)
+
+
 def test_polynomial_rows_in_chunks_at_full_size(hip_library):
     """fp64 Paul at the bench target: 150 MB of coefficient planes, so the polynomial rows go through in two chunks (planes
     computed, consumed, next chunk).  Same bits as all rows at once; a few rows against the forms the polynomial one replaced
