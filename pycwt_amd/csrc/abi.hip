@@ -13,7 +13,7 @@ int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, 
   if (nrows < 1 || nrows > p->max_rows) return fail(CWT_EINVAL, "nrows must be in [1, max_rows]");
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
-  const std::vector<double> key = call_key(0, {double(mother), param, dt, double(nrows), have_signal ? 1.0 : 0.0, double(ncols)},
+  const std::vector<double> key = call_key(0, {p->tolerance, double(mother), param, dt, double(nrows), have_signal ? 1.0 : 0.0, double(ncols)},
                                            {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -368,9 +368,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
 int cwt_plan_set_tolerance(cwt_plan* p, double rel_tol) {
   if (!p) return fail(CWT_EINVAL, "plan is NULL");
   if (!(rel_tol >= 0) || rel_tol > 1e-2) return fail(CWT_EINVAL, "tolerance must be in [0, 1e-2] (0 = default)");
-  if (rel_tol != p->tolerance) for (auto& t : p->slots) t.key.clear();   // the classification depends on it (an unchanged value
-  p->tolerance = rel_tol;                                                  // keeps the cached row tables: a Monte-Carlo loop
-  return CWT_OK;                                                           // re-measures it at its first draw)
+  p->tolerance = rel_tol;     // (part of the row tables' cache key: a loop whose measured target flips between two values -- Monte-Carlo
+  return CWT_OK;              // surrogates near a threshold of the automatic mode -- keeps both tables; a rebuild at N = 2^23 is 1.6 s)
 }
 
 int cwt_plan_set_auto_tolerance(cwt_plan* p, double target) {
@@ -594,7 +593,7 @@ int cwt_transform_rows_batch(cwt_plan* p, const void* xhat_dev, int nbatch, int6
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
   const int total = nbatch * nrows;
-  const std::vector<double> key = call_key(2, {double(mother), param, dt, double(nbatch), double(xhat_ld), double(nrows)},
+  const std::vector<double> key = call_key(2, {p->tolerance, double(mother), param, dt, double(nbatch), double(xhat_ld), double(nrows)},
                                            {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -633,7 +632,7 @@ int cwt_transform_batch(cwt_plan* p, const void* x_dev, int nbatch, int64_t x_ld
   if (!(dt > 0) || !std::isfinite(dt)) return fail(CWT_EINVAL, "dt must be positive");
   HIPCHECK(hipSetDevice(p->device));
   const int total = nbatch * nrows;
-  const std::vector<double> key = call_key(3, {double(mother), param, dt, double(nbatch), double(nrows), double(ncols)},
+  const std::vector<double> key = call_key(3, {p->tolerance, double(mother), param, dt, double(nbatch), double(nrows), double(ncols)},
                                            {{scales, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -710,7 +709,7 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
   if (ncols < 1 || ncols > p->N || ldw < ncols) return fail(CWT_EINVAL, "need 1 <= ncols <= nfft and ldw >= ncols");
   if (spec_ld != 0 && spec_ld < p->N) return fail(CWT_EINVAL, "spec_ld must be 0 (shared) or >= nfft");
   HIPCHECK(hipSetDevice(p->device));
-  const std::vector<double> key = call_key(1, {double(mother), param, double(spec_ld), double(nrows)},
+  const std::vector<double> key = call_key(1, {p->tolerance, double(mother), param, double(spec_ld), double(nrows)},
                                            {{a, nrows}, {amp_re, nrows}, {amp_im, nrows}});
   if (!select_table(p, key)) {
     double cre, cim;
@@ -916,7 +915,7 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
       }
       if (p->auto_target > 0) {                            // (round-off costs such transforms nothing: no need to look)
         const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
-        if (floor_tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = floor_tol; }
+        p->tolerance = floor_tol;
       }
       int rc = grow(&p->hxhat, &p->hxhat_bytes, xh_b, p->stream);
       if (rc) return rc;
@@ -957,7 +956,7 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
   if (W_host && p->auto_target > 0 && p->logN <= p->loglmax) {
     // single-workgroup transforms compute every bin of every row anyway: round-off costs nothing, no need to look
     const double floor_tol = p->prec == 64 ? kDefaultTolerance64 : kDefaultTolerance32;
-    if (floor_tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = floor_tol; }
+    p->tolerance = floor_tol;
   } else if (W_host && p->auto_target > 0) {
     // accuracy target of THIS call = auto_target / (dynamic range of its spectrum relative to white noise), a power of
     // ten (so that calls with like spectra share one cached row table), never looser than the target itself
@@ -965,7 +964,7 @@ int cwt_execute_host(cwt_plan* p, const void* x_host, int64_t n0, int mother, do
     double tol = 0;
     if (!rc) rc = cwt_plan_auto_tolerance(p, p->hxhat, p->auto_target, &tol);
     if (rc) return rc;
-    if (tol != p->tolerance) { for (auto& t : p->slots) t.key.clear(); p->tolerance = tol; }
+    p->tolerance = tol;
   }
   if (W_host) rc = cwt_transform(p, p->hx, n0, mother, param, dt, scales, nrows, p->hxhat, p->hW, n0, n0);
   else rc = cwt_forward_fft(p, p->hx, n0, p->hxhat);

@@ -144,7 +144,7 @@ struct cwt_plan {
   void* hx = nullptr; size_t hx_bytes = 0;
   void* hxhat = nullptr; size_t hxhat_bytes = 0;
   void* hW = nullptr; size_t hW_bytes = 0;
-  // Classified row tables with their device copies.  Two slots, least recently used one rebuilt on a miss, so that
+  // Classified row tables with their device copies.  Four slots (the accuracy target is part of the key), least recently used one rebuilt on a miss, so that
   // callers that alternate between two kinds of calls with fixed arguments (the coherence pipeline: cwt rows, then
   // the smoothing filter rows, draw after draw) build and upload each table once.  No host synchronisation on the
   // way: every slot has its own pinned staging buffer and an event that marks its last copy as done.
@@ -200,7 +200,7 @@ struct cwt_plan {
     uint64_t used = 0;
     uint64_t build_id = 0;               // changes whenever the table is rebuilt (graphs captured over it are stale then)
   };
-  RowTable slots[2];
+  RowTable slots[4];
   RowTable* rt = &slots[0];
   uint64_t tick = 0;
   int split[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rows: single-workgroup, band-limited K <= 1024 with <= 4 terms, two-pass,
