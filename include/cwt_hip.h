@@ -142,7 +142,9 @@ int cwt_plan_set_option(cwt_plan* plan, const char* key, int64_t value);
  * know their spectra pass a looser target and get the faster forms (bench.py: 1e-9 / 3e-5 on white noise; error and speed
  * per target: profiles/r04_tolerance_sweep.txt); callers that do not can measure D (cwt_spectrum_range) or let
  * cwt_execute_host do it per call (cwt_plan_set_auto_tolerance).  Also reachable as the option "tolerance_neglog10"
- * (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces the default of new plans. */
+ * (integer n -> 10^-n); the environment variable CWT_TOLERANCE, read by cwt_plan_create, replaces the default of new plans.
+ * The target is part of the key of the plan's cached row tables (four of them): alternating between two targets rebuilds
+ * nothing. */
 int cwt_plan_set_tolerance(cwt_plan* plan, double rel_tol);
 /* target > 0: cwt_execute_host (the host-buffer call, which synchronises anyway) sets the plan's tolerance per call to
  * cwt_plan_auto_tolerance(target) of that call's spectrum.  0 = off (the plan's own tolerance is used).  The

@@ -225,6 +225,7 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
     const double t = std::atof(e);
     if (t > 0 && t <= 1e-2) p->tolerance = t;
   }
+  if (const char* e = std::getenv("CWT_QUEUE_PROBE")) p->queue_probe = std::atoi(e) != 0;   // (diagnostic: plans the caller does not create itself)
   int rc = precision == 64 ? build_tables<double>(p) : build_tables<float>(p);
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {

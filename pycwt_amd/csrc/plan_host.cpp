@@ -1242,6 +1242,9 @@ bool select_table(cwt_plan* p, const std::vector<double>& key) {
   if (!key.empty())
     for (auto& t : p->slots)
       if (t.key == key) { p->rt = &t; t.used = p->tick; return true; }
+  static const bool verbose = std::getenv("CWT_TABLES_VERBOSE") != nullptr;      // (diagnostic: which calls rebuild a row table)
+  if (verbose && key.size() > 4)
+    std::fprintf(stderr, "[cwt] row table miss: kind %g tolerance %g mother %g rows/param %g %g (key of %zu)\n", key[0], key[1], key[2], key[3], key[4], key.size());
   cwt_plan::RowTable* lru = &p->slots[0];
   for (auto& t : p->slots) if (t.used < lru->used) lru = &t;
   lru->key.clear();

@@ -19,8 +19,10 @@ cp $S/timeline_c2.txt $P/r05_timeline_c2.txt
   echo "# call c + 1 beside the rows of call c: slower (0.146-0.199 against 0.133-0.136 ms per rank), EXPERIMENTS.md R5.2 / R5.3."
 } > $P/r05_shards.txt
 { echo "# BASELINE config 5 on ONE GPU (tests/perf/wct_bench.py 20 0.25 12; round 5).  NumPy in / out unless marked device-resident."
-  echo "# ms per draw = (time of 12 draws incl. the first draw's accuracy measurement and row tables) / 12; steady state 53-55 ms per"
-  echo "# draw for both kinds of device surrogates (tools/lab/mc_time.py: first call of a new tolerance 1.6 s, then 52.6-53.9 ms each)."
+  echo "# Monte-Carlo: a call = a fixed part (tens of GB of scratch allocated at its first draw and freed at its end, the first draw's"
+  echo "# look at the spectra, row tables of an accuracy target the plan has not seen yet) + draws; the script times calls of 2 and 12"
+  echo "# draws and reports both parts (a first version divided ONE call by its draws: 55 ... 450 ms per draw depending on what the call"
+  echo "# before it had left in the allocator and the table cache)."
   grep -v amdgpu.ids $S/wct.txt; } > $P/r05_wct.txt
 for c in paul64 dog64; do cp $S/bench_${c}_line.json $P/r05_bench_${c}_line.json; done
 tail -4 $S/pytest_gpu.log > $P/r05_pytest_gpu.txt; tail -1 $S/smoke.log >> $P/r05_pytest_gpu.txt
