@@ -527,10 +527,15 @@ def config5_callers(logn=20, dj=0.25):
         J = int(np.round(np.log2(n * 1.0 / s0) / dj))
         kw = dict(progress=False, cache=False, rng=rng_name)
         np.random.seed(3)
-        pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=2, **kw)            # plans, row tables
-        t0 = time.perf_counter()
-        pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=draws, **kw)
-        return (time.perf_counter() - t0) / draws * 1e3
+        def call(count):
+            t0 = time.perf_counter()
+            pycwt_amd.wct_significance(0.5, 0.4, 1.0, dj, s0, J, mc_count=count, **kw)
+            return time.perf_counter() - t0
+        call(2)                                                                             # plans, row tables
+        # a call = a fixed part (tens of GB of scratch allocated at its first draw, freed at its end; the first draw's look at the
+        # spectra) + draws: the difference of two calls is the draws alone (tests/perf/wct_bench.py prints both parts)
+        t2, tm = call(2), call(draws + 2)
+        return (tm - t2) / draws * 1e3
     try:
         x_ms, shape = best(lambda: pycwt_amd.xwt(y1, y2, 1.0, dj))
         w_ms, _ = best(lambda: pycwt_amd.wct(y1, y2, 1.0, dj, sig=False))
