@@ -923,6 +923,8 @@ def main():
         out["extra"]["c1_nino3_latency"] = config1_latency()
         out["extra"]["c4_batch"] = config4_batch(rt)
         out["extra"]["c5_xwt_wct"] = config5_callers()
+        import pycwt_amd
+        pycwt_amd.release_scratch()                # (the shim keeps the work matrices of its last calls: tens of GB after config 5)
         for c in ("c3_paul", "c3_dog", "paul64"):
             # (paul64: not a BASELINE config -- config 3 is quoted in fp32 -- but the reference's own arithmetic for Paul,
             # mothers.py:118-122, and what pycwt_amd.cwt(..., 'paul') runs by default; parity on the rows the reference keeps)

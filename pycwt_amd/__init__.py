@@ -8,9 +8,9 @@ through the C ABI of include/cwt_hip.h.  Importing this package does not need a 
 from . import helpers, mothers
 from .helpers import ar1, ar1_spectrum, fft, fft_kwargs, find, get_cache_dir, rednoise
 from .mothers import DOG, MexicanHat, Morlet, Paul
-from .wavelet import (DeviceCoherence, DeviceTransform, cwt, cwt_batch, cwt_device, icwt, set_tolerance, significance, wct,
-                      wct_device, wct_significance, xwt, xwt_device)
+from .wavelet import (DeviceCoherence, DeviceTransform, cwt, cwt_batch, cwt_device, icwt, release_scratch, set_tolerance,
+                      significance, wct, wct_device, wct_significance, xwt, xwt_device)
 
 __version__ = "0.1.0"
-__all__ = ["cwt", "cwt_batch", "cwt_device", "DeviceTransform", "DeviceCoherence", "wct_device", "xwt_device", "icwt", "set_tolerance", "significance", "xwt", "wct", "wct_significance", "Morlet", "Paul", "DOG",
+__all__ = ["cwt", "cwt_batch", "cwt_device", "DeviceTransform", "DeviceCoherence", "wct_device", "xwt_device", "icwt", "set_tolerance", "release_scratch", "significance", "xwt", "wct", "wct_significance", "Morlet", "Paul", "DOG",
            "MexicanHat", "ar1", "ar1_spectrum", "rednoise", "find", "get_cache_dir", "helpers", "mothers", "fft", "fft_kwargs"]

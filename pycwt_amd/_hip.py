@@ -553,6 +553,9 @@ class Plan:
                 "ols": c[5], "aols": c[6], "poly": c[7]}
 
 
+on_allocation_failure: list = []      # callables that give device memory back; run once before an allocation is retried
+
+
 class DeviceBuffer:
     """Device memory owned through cwt_malloc / cwt_free (used by the NumPy-only host path)."""
 
@@ -561,7 +564,12 @@ class DeviceBuffer:
         self.device = device
         self.nbytes = int(nbytes)
         p = _P()
-        self.lib.check(self.lib.cwt_malloc(device, C.byref(p), self.nbytes))
+        try:
+            self.lib.check(self.lib.cwt_malloc(device, C.byref(p), self.nbytes))
+        except HipError:
+            for release in list(on_allocation_failure):       # (the shim's pool of kept work matrices, wavelet.release_scratch)
+                release()
+            self.lib.check(self.lib.cwt_malloc(device, C.byref(p), self.nbytes))
         self.ptr = p.value
 
     def free(self):

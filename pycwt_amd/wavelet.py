@@ -684,6 +684,66 @@ def xwt_device(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wave
     return T1, std1 * std2 * pk * chi2.ppf(significance_level, dof) / dof
 
 
+# Work matrices that a call has finished with are kept for the next call instead of going back to the driver: a Monte-Carlo
+# call works in ~60 GB (77 scales x 6 M samples), and allocating / freeing that took 0.1 ... 4.7 s per call on the MI355X
+# boxes, more than the draws of a short call.  Bounded (PYCWT_AMD_SCRATCH_POOL_GB, default 64; 0 = keep nothing), emptied by
+# `release_scratch()` and whenever an allocation fails.
+_POOL_LOCK = threading.Lock()
+_POOL: dict = {}                  # (library, device, nbytes) -> [DeviceBuffer]
+_POOL_HELD = [0]
+
+
+def _pool_limit():
+    try:
+        return int(float(os.environ.get("PYCWT_AMD_SCRATCH_POOL_GB", "64")) * 2 ** 30)
+    except ValueError:
+        return 0
+
+
+def release_scratch():
+    """Free the device memory kept from earlier calls (see PYCWT_AMD_SCRATCH_POOL_GB)."""
+    with _POOL_LOCK:
+        bufs = [b for v in _POOL.values() for b in v]
+        _POOL.clear()
+        _POOL_HELD[0] = 0
+    for b in bufs:
+        b.free()
+
+
+_hip.on_allocation_failure.append(release_scratch)
+
+
+def _pool_take(lib, device, nbytes):
+    with _POOL_LOCK:
+        v = _POOL.get((id(lib), device, int(nbytes)))
+        if v:
+            _POOL_HELD[0] -= int(nbytes)
+            return v.pop()
+    return None
+
+
+def _pool_give(bufs):
+    if not bufs:
+        return
+    keep, limit = [], _pool_limit()
+    with _POOL_LOCK:
+        for b in bufs:
+            if b.ptr and _POOL_HELD[0] + b.nbytes <= limit:
+                _POOL_HELD[0] += b.nbytes
+                keep.append(b)
+    kept = set(map(id, keep))
+    for b in bufs:
+        if id(b) not in kept:
+            b.free()                                   # (hipFree: waits for the device, as every free did before the pool)
+    if keep:
+        # what hipFree did implicitly: nothing queued on ANY stream (the caller's own kernels included) still uses the buffers
+        # when their next owner gets them
+        _hip.DeviceBuffer(256, keep[0].device, keep[0].lib).free()
+        with _POOL_LOCK:
+            for b in keep:
+                _POOL.setdefault((id(b.lib), b.device, b.nbytes), []).append(b)
+
+
 class _Scratch:
     """Device buffers of one wct evaluation, freed together."""
 
@@ -691,7 +751,10 @@ class _Scratch:
         self.device, self.bufs = device, []
 
     def new(self, nbytes):
-        b = _hip.DeviceBuffer(nbytes, self.device)
+        lib = _hip.load()
+        b = _pool_take(lib, self.device, nbytes)
+        if b is None:
+            b = _hip.DeviceBuffer(nbytes, self.device, lib)      # (an allocation that fails empties the pool and tries again)
         self.bufs.append(b)
         return b
 
@@ -705,9 +768,8 @@ class _Scratch:
         return b
 
     def free(self):
-        for b in self.bufs:
-            b.free()
-        self.bufs = []
+        bufs, self.bufs = self.bufs, []
+        _pool_give(bufs)
 
 
 def _smooth_on_device(plan, mother, T, rows, n, dt, dj, sj, spec, tmp, out):

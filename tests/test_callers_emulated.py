@@ -253,3 +253,35 @@ def test_wct_significance_with_surrogates_made_on_the_device(emulated, tmp_path,
     assert len(list(tmp_path.glob("wct_sig_*_devrng.gz"))) == 1
     with pytest.raises(ValueError):
         pycwt_amd.wct_significance(*al, rng="gpu", **kw)
+
+
+def test_scratch_of_a_call_is_kept_for_the_next(emulated, monkeypatch):
+    """Work matrices go back to a bounded pool instead of to the driver (a Monte-Carlo call's ~60 GB cost seconds to allocate
+    and free): the second call allocates nothing, results are the same, the bound and release_scratch() hold."""
+    import pycwt_amd
+    from pycwt_amd import wavelet as w, _hip
+    pycwt_amd.release_scratch()
+    made = []
+    orig = _hip.DeviceBuffer.__init__
+
+    def counting(self, nbytes, device=0, lib=None):
+        made.append(int(nbytes))
+        orig(self, nbytes, device, lib)
+    monkeypatch.setattr(_hip.DeviceBuffer, "__init__", counting)
+    rng = np.random.default_rng(8)
+    y1, y2 = rng.standard_normal(600), rng.standard_normal(600)
+    a = pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
+    first = len([n for n in made if n > 256])
+    assert first > 0 and w._POOL_HELD[0] > 0
+    made.clear()
+    b = pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
+    assert [n for n in made if n > 256] == []                    # every matrix came from the pool
+    for u, v in zip(a[:2], b[:2]):
+        assert np.array_equal(u, v)
+    held = w._POOL_HELD[0]
+    assert held == sum(x.nbytes for v in w._POOL.values() for x in v)
+    pycwt_amd.release_scratch()
+    assert w._POOL_HELD[0] == 0 and not w._POOL
+    monkeypatch.setenv("PYCWT_AMD_SCRATCH_POOL_GB", "0")          # keep nothing
+    pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
+    assert w._POOL_HELD[0] == 0 and not any(w._POOL.values())
