@@ -763,6 +763,12 @@ def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True):
         idle = wl.timed(args.steps, args.warmup)
         primed_steps = wl.prime(PRIME_MS)
         out = wl.timed(args.steps, args.warmup)
+        if args.shard:
+            # the single-GPU diagnostic of a rank's share: the faster of two timed regions (about one region in fifteen comes
+            # out 50 % long on these boxes for no reason visible in the kernel trace; the headline keeps its ONE region)
+            again = wl.timed(args.steps, args.warmup)
+            if again["ms_per_step"] < out["ms_per_step"]:
+                out = again
         out["from_idle"] = {"ms_per_step": idle["ms_per_step"], "value": idle["value"],
                             "note": "the same W warm-up + K timed steps started on an idle device (clocks still ramping)"}
         out["effective_warmup_steps"] = args.warmup + primed_steps + args.warmup + args.steps    # everything that ran before
