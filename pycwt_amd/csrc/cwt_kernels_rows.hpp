@@ -226,8 +226,8 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
 }
 
 // ---- complex64: TWO blocks of a row per workgroup -------------------------------------------------------------------
-// The block transforms are bound by the issue rate of the vector ALU (a 4096-point tile is ~1000 instructions per thread,
-// 2.4 us per row of 2^20 outputs against 1.0 for its bytes).  gfx950 issues packed fp32 instructions -- two results per slot --
+// A block transform is ~1000 vector instructions per thread of a 4096-point tile (2.3 us per row of 2^20 outputs against 1.0 for
+// its bytes), of which the compiler packs a third on its own.  gfx950 issues packed fp32 instructions -- two results per slot --
 // so in complex64 a workgroup transforms blocks 2u and 2u + 1 of its row TOGETHER: every data register is a pairf (block 2u in
 // the low half, 2u + 1 in the high half), filter table, twiddles and addresses are shared, the exchange buffer holds 8-byte
 // elements.  The odd block out at the end of a row is transformed twice and stored once (nlim of the second half <= 0).
