@@ -285,3 +285,30 @@ def test_scratch_of_a_call_is_kept_for_the_next(emulated, monkeypatch):
     monkeypatch.setenv("PYCWT_AMD_SCRATCH_POOL_GB", "0")          # keep nothing
     pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
     assert w._POOL_HELD[0] == 0 and not any(w._POOL.values())
+
+
+def test_failed_allocation_empties_the_scratch_pool_and_retries(emulated, monkeypatch):
+    """Memory kept from finished calls must never be what makes the next allocation fail: a failing cwt_malloc runs the release
+    hook (the pool goes back to the driver) and is tried once more."""
+    import pycwt_amd
+    from pycwt_amd import wavelet as w, _hip
+    rng = np.random.default_rng(9)
+    y1, y2 = rng.standard_normal(400), rng.standard_normal(400)
+    pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
+    assert w._POOL_HELD[0] > 0
+    lib = _hip.load()
+    real, state = lib.cwt_malloc, {"fail": 1, "calls": 0}
+
+    def flaky(device, pptr, nbytes):
+        state["calls"] += 1
+        if state["fail"]:
+            state["fail"] -= 1
+            return -2                                   # CWT_ENOMEM
+        return real(device, pptr, nbytes)
+    monkeypatch.setattr(lib, "cwt_malloc", flaky)
+    buf = _hip.DeviceBuffer(1 << 20, lib=lib)
+    assert buf.ptr and state["calls"] == 2 and w._POOL_HELD[0] == 0 and not w._POOL
+    buf.free()
+    state["fail"] = 2                                   # still failing after the release: the error reaches the caller
+    with pytest.raises(_hip.HipError):
+        _hip.DeviceBuffer(1 << 20, lib=lib)
