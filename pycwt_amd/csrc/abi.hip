@@ -132,11 +132,11 @@ int cwtd::ensure_distinct_queues(cwt_plan*) { return CWT_OK; }     // (the CPU s
 #else
 __global__ void k_queue_probe_wait(int* flag, int* seen, long long ticks) {
   const long long t0 = wall_clock64();                              // 100 MHz
-  int s = 0;
+  int s = 0, turns = 0;
   do {
     s = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (!s) __builtin_amdgcn_s_sleep(16);
-  } while (!s && wall_clock64() - t0 < ticks);
+    if (!s) __builtin_amdgcn_s_sleep(16);                           // ~0.5 us
+  } while (!s && wall_clock64() - t0 < ticks && ++turns < 20000);   // (the turn count bounds the wait whatever the clock does)
   *seen = s;
 }
 __global__ void k_queue_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
