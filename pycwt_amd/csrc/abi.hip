@@ -341,6 +341,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "aols") p->aols = value != 0;
   else if (k == "aols_zc") p->aols_zc = value != 0;
   else if (k == "poly") p->poly = value != 0;
+  else if (k == "coef_small") p->coef_small = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
   else if (k == "queue_probe") { p->queue_probe = value != 0; }
   else if (k == "poly_chunk_mb") { if (value < 0 || value > 4096) return fail(CWT_EINVAL, "poly_chunk_mb in [0, 4096] (0 = one chunk)"); p->poly_chunk_mb = int(value); }
@@ -355,6 +356,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
+  else if (k == "serial_rows") { if (value < 0 || value > 2) return fail(CWT_EINVAL, "serial_rows: 0, 1 or 2"); p->serial_rows = int(value); }
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "tolerance_neglog10") {   // integer alias of cwt_plan_set_tolerance for option sweeps: 10^-value; 0 = default
@@ -531,11 +533,26 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
                         : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
       if (r) return r;
     }
+    // serial_rows = 2: the forward FFT on side stream 0 (the bands + coefficients of the polynomial rows follow it there), so that
+    // the first overlap-save rows start on the caller's stream as soon as their block spectra exist
+    const bool fft_aside = p->serial_rows == 2 && serial_schedule(p, p->ols_launched != 0);
+    hipStream_t caller = p->stream;
+    if (fft_aside) {
+      if (!p->ols_launched) HIPCHECK(hipEventRecord(p->ev_fork, caller));
+      HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
+      p->stream = p->side[0];
+    }
     r = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
                       : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
+    p->stream = caller;
+    if (fft_aside && !r) {
+      HIPCHECK(hipEventRecord(p->ev_a[1], p->side[0]));
+      p->spectrum_ready = p->ev_a[1];
+    }
     if (!r) r = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                               : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
     p->ols_launched = 0;
+    p->spectrum_ready = nullptr;
     return r;
   };
   if (!p->graph || p->profile) return enqueue();

@@ -716,6 +716,98 @@ k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, co
 #undef CWT_POLY_CASE
 }
 
+// K' = 8192 / 16384 on 256-thread workgroups (option "coef_small"): the 512- / 1024-thread tiles above take half a CU / a whole
+// CU each and do not get one while the overlap-save rows keep refilling the chip with 256-thread workgroups (k_poly_coef<14>:
+// 346 us for 30 us of work, and k_poly_rows waits for it).  One decimation-in-frequency step splits a K'-point transform
+// into S = K' / 4096 independent 4096-point transforms, one workgroup each:
+//     X[S m + h] = IFFT_4096( u_h )[m],   u_h[q] = ( sum_{a < S} x[q + 4096 a] e^{2 pi i a h / S} ) e^{2 pi i q h / K'},   q < 4096
+// -- every workgroup reads the whole band (S loads per point, from the cache) and stores every S-th coefficient of its plane; the
+// S workgroups of a job are eight workgroup ids apart (same XCD, same L2: the partial lines merge there).
+template <typename T, int LOGS>
+__device__ __forceinline__ void poly_coef_split_body(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows,
+                                                     const cplx<T>* __restrict__ tw_all, const PolyClass& pc,
+                                                     unsigned local_wg, cplx<T>* __restrict__ coef, T* lds) {
+  constexpr int S = 1 << LOGS, LOGK = 12 + LOGS, K = 1 << LOGK, NT = 256;
+  using F = ct::Fft<T, 12, 0, false>;
+  F f;
+  f.t = 0;
+  f.j = threadIdx.x;
+  const unsigned idx = local_wg % unsigned(8 * S), job = (local_wg / unsigned(8 * S)) * 8u + (idx & 7u), h = idx >> 3;
+  const int rowi = int(job) / pc.ndeg, d = int(job) - rowi * pc.ndeg;
+  if (rowi >= pc.nrows) return;                               // (uniform over the workgroup)
+  const RowDesc rd = rows[pc.row_first + rowi];
+  if (d > rd.nterms) return;
+  const int klo = -(rd.nband >> 1);
+  const T tscale = T(3.14159265358979323846 / double(K));
+  const T ifact = T(inv_factorial(d));
+  const cplx<T>* y = yb + rd.aux_off + f.j;
+  T re[16], im[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { re[e] = T(0); im[e] = T(0); }
+#pragma unroll 1
+  for (int a = 0; a < S; ++a) {
+    const unsigned turn = (unsigned(a) * h * unsigned(4 / S) + unsigned(d)) & 3u;     // e^{2 pi i a h / S} i^d as quarter turns
+#pragma unroll
+    for (int g = 0; g < 16; g += 8) {                         // eight loads in flight (the accumulators hold 64 registers already)
+      cplx<T> v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = y[(g + e) * NT + (a << 12)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = f.j + (g + e) * NT + (a << 12);
+        const int kap = klo + ((q - klo) & (K - 1));
+        const T pw = ipow<T>(T(kap) * tscale, d) * ifact;     // theta^d / d!
+        T vr = v[e].x * pw, vi = v[e].y * pw;
+        if (turn & 1u) { const T tmp = vr; vr = -vi; vi = tmp; }
+        if (turn & 2u) { vr = -vr; vi = -vi; }
+        re[g + e] += vr; im[g + e] += vi;
+      }
+      if (g == 0) { keep_here(re[0]); keep_here(im[0]); }      // (keeps the second group's loads behind the first group's sums)
+    }
+  }
+  if (h) {
+    const cplx<T>* tk = tw_all + (K - 2);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+      cplx<T> w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = tk[unsigned(f.j + (g + e) * NT) * h];     // q h < 3 * 4096 <= K' - 1: no wrap
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T x = re[g + e], yv = im[g + e];
+        re[g + e] = x * w[e].x - yv * w[e].y;
+        im[g + e] = x * w[e].y + yv * w[e].x;
+      }
+    }
+  }
+  f.run(re, im, lds, tw_all + (4096 - 2));
+  cplx<T>* out = coef + rd.tab_off + (long(d) << LOGK) + (long(f.j) << LOGS) + h;   // plane d of the row, element S m + h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[long(e * NT) << LOGS] = mk<T>(re[e], im[e]);
+}
+
+// every class of a chunk in ONE launch of 256-thread workgroups: PolyClass::wg_first1 = the class's first workgroup in it
+template <typename T>
+__global__ void __launch_bounds__(256, 4)
+k_poly_coef_all(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ tw_all,
+                PolyClasses cls, cplx<T>* __restrict__ coef) {
+  HIP_DYNAMIC_SHARED(double2, lds_raw)
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  PolyClass pc = cls.c[0];
+#pragma unroll
+  for (int i = 1; i < POLY_MAX_CLASSES; ++i)
+    if (i < cls.n && int(blockIdx.x) >= cls.c[i].wg_first1) pc = cls.c[i];
+  const unsigned local = blockIdx.x - unsigned(pc.wg_first1);
+#define CWT_POLY_CASE(LK) case LK: poly_coef_body<T, LK, 12>(yb, rows, tw_all, pc, local, coef, lds); break;
+  switch (pc.logK) {
+    CWT_POLY_CASE(8) CWT_POLY_CASE(9) CWT_POLY_CASE(10) CWT_POLY_CASE(11) CWT_POLY_CASE(12)
+    case 13: poly_coef_split_body<T, 1>(yb, rows, tw_all, pc, local, coef, lds); break;
+    case 14: poly_coef_split_body<T, 2>(yb, rows, tw_all, pc, local, coef, lds); break;
+    default: break;
+  }
+#undef CWT_POLY_CASE
+}
+
 // Stage 2.  One workgroup = 256 lanes x POLY_PASSES passes; a lane stores 16 bytes per pass (one complex128 or two adjacent
 // complex64 outputs).  sc[i][d] = a_d[m0 + i] for the intervals m0 ... the workgroup touches.
 template <typename T, int D>

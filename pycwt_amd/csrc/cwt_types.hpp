@@ -94,6 +94,7 @@ struct PolyClass {
   int ndeg;        // degrees computed per row of this class = 1 + the largest degree in it
   int wg_first;    // first workgroup of the class in ITS k_poly_coef launch (one launch per tile size: 4096-point tiles for
                    // K' <= 4096, 8192 for K' = 8192, 16384 for K' = 16384)
+  int wg_first1;   // ... and in the single launch of k_poly_coef_all (256-thread workgroups for every K'; a multiple of 8)
 };
 struct PolyClasses {
   PolyClass c[POLY_MAX_CLASSES];

@@ -338,10 +338,11 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
   }, st);
 }
 template <typename T>
-int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, hipEvent_t after_first = nullptr) {
   int rc = CWT_OK;
   {
     for (int g = 0; g < 2 && !rc; ++g) {
+      if (g == 1 && after_first) HIPCHECK(hipEventRecord(after_first, st));     // the half-size tiles' spectra exist
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows) continue;
       for (int d = 0; d < 3 && !rc; ++d) {
@@ -375,12 +376,12 @@ int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int g_only = -1) {
   int rc = CWT_OK;
   for (int g = 0; g < 2 && !rc; ++g) {        // the half-size tiles first (by far the longer launch since the rows with long
                                               // halos went to the polynomial form), then the default tile's rows
     const auto& G = p->rt->ols_grp[g];
-    if (!G.nrows) continue;
+    if (!G.nrows || (g_only >= 0 && g != g_only)) continue;
     switch (G.logp) {
       case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
       case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
@@ -392,8 +393,11 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
 
 // Rows clipped at Nyquist (k_aols_*): band-passed complex signal x_M = IFFT_N(xhat mask) through the two-pass kernels
 // (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
+// st_rows != nullptr (one signal only): the band-passed signal and its block spectra on st, `ready` recorded behind them,
+// the rows on st_rows behind that event.
 template <typename T, int LOGP>
-int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
+                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
@@ -429,12 +433,18 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
       hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st, xm,
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
+    hipStream_t sr = st;
+    if (!rc && st_rows && nb == 1) {
+      HIPCHECK(hipEventRecord(ready, st));
+      HIPCHECK(hipStreamWaitEvent(st_rows, ready, 0));
+      sr = st_rows;
+    }
     if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
-      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds_rows, st,
+      hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds_rows, sr,
                          static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
                          static_cast<const T*>(rt->agt_dev), static_cast<const cplx<T>*>(p->tw_all), g,
                          static_cast<const cplx<T>*>(xhat_dev), long(p->N >> 1), W, long(ldw), long(ncols));
-    }, st);
+    }, sr);
     if (rc) return rc;
   }
   return CWT_OK;
@@ -466,13 +476,14 @@ int launch_aols_second(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ld
   return rc;
 }
 template <typename T>
-int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
+                hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
   int rc = CWT_OK;
   switch (p->rt->aols_logp) {
-    case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st); break;
+    case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, st_rows, ready); break;
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
-  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, st);
+  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, st_rows ? st_rows : st);
   return rc;
 }
 
@@ -497,8 +508,12 @@ int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, int chu
                          xhat, rows + r0, mo, twn_of<T>(p), p->logN, band);
   }, st);
   if (rc) return rc;
-  // largest tiles first: the 16384-point workgroups take a whole CU each and should find the chip as empty as it gets
   const cplx<T>* tw = static_cast<const cplx<T>*>(p->tw_all);
+  if (p->coef_small)         // every class on 256-thread workgroups, one launch (k_poly_coef_all)
+    return timed_launch(p, KC_POLY_COEF, [&] {
+      hipLaunchKernelGGL((k_poly_coef_all<T>), dim3(unsigned(ch.wgs_all)), dim3(256), ((size_t(1) << 12) + (size_t(1) << 8)) * sizeof(T), st,
+                         static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, st);
+  // largest tiles first: the 16384-point workgroups take a whole CU each and should find the chip as empty as it gets
   auto lds_of = [](int lp) { return ((size_t(1) << lp) + (size_t(1) << (lp - 4))) * sizeof(T); };
   const bool split = st2 && ch.wgs[2] && (ch.wgs[1] || ch.wgs[0]);
   hipStream_t s2 = split ? st2 : st;
@@ -536,6 +551,101 @@ int launch_poly_rows(cwt_plan* p, int chunk, cplx<T>* W, int64_t ldw, int64_t nc
       hipLaunchKernelGGL((k_poly_rows<T>), dim3(unsigned((ncols + per_wg - 1) / per_wg), std::min(kMaxGridY, ch.nrows - r0)),
                          dim3(256), lds2, st, rows + r0, coef, twn_of<T>(p), p->logN, W, long(ldw), long(ncols));
   }, st);
+}
+
+// Two-pass rows (forms T), chunk by chunk on the plan's stream through the one intermediate buffer.
+template <typename T>
+int launch_wide_rows(cwt_plan* p, const void* xhat_dev, const Mother& mo, cplx<T>* W, int64_t ldw, int64_t ncols) {
+  const int logN = p->logN, logP = std::min(p->log_wg_points, logN), threads = 1 << (logP - 4);
+  const size_t lds = (size_t(1) << logP) * sizeof(T);
+  const int logK = two_pass_logk(p), logR = logN - logK;
+  const int chunk = balanced_chunk(p, p->rt->n_wide);
+  const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
+  int rc = ensure_z(p, chunk);
+  if (rc) return rc;
+  cplx<T>* Z = static_cast<cplx<T>*>(p->Z);
+  for (int c = 0; c < nchunks; ++c) {
+    const int first = c * chunk, cnt = std::min(chunk, p->rt->n_wide - first);
+    const RowDesc* rows = p->rt->rows_dev + p->rt->wide_first + first;
+    rc = timed_launch(p, KC_PASS_A, [&] {
+      if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, 0L, Z, p->stream)) return;
+      hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
+                         xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, 0L, Z);
+    });
+    if (rc) return rc;
+    rc = timed_launch(p, KC_PASS_B, [&] {
+      if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, p->stream)) return;
+      hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
+                         static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), twn_of<T>(p), logN, logK,
+                         logP - logK, W, long(ldw), long(ncols));
+    });
+    if (rc) return rc;
+  }
+  return CWT_OK;
+}
+
+// The schedule of a long transform with polynomial rows (option "serial_rows", default): every kernel that WRITES W runs
+// on the caller's stream, one after the other -- overlap-save rows (half-size tiles, then the default tile), rows on the
+// band-passed signal, two-pass rows, polynomial rows -- and everything they need is prepared on the side streams beside the
+// first of them: block spectra on side stream 1 (queued before the forward FFT by cwt_transform), behind them the band-passed
+// signal and its block spectra; bands + interval coefficients on side stream 0 (+ side2).  Why: heavy kernels side by side cost
+// more than one after the other (EXPERIMENTS R5.2), a stream-to-stream hand-over costs 15-20 us where the waiting stream is idle
+// -- so the hand-overs sit where the event completed long before the wait is reached, and the step ends on the caller's stream
+// (the next call, or whatever the caller queues, follows at a kernel boundary instead of a join).
+template <typename T>
+int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void* W_dev, int64_t ldw, int64_t ncols,
+                       hipEvent_t spectrum_ready) {
+  const cwt_plan::RowTable* rt = p->rt;
+  const cplx<T>* xhat = static_cast<const cplx<T>*>(xhat_dev);
+  cplx<T>* W = static_cast<cplx<T>*>(W_dev);
+  hipStream_t M = p->stream, S0 = p->side[0], S1 = p->side[1];
+  int rc = CWT_OK;
+  // the one intermediate buffer serves the band-passed signal (side stream 1) and the two-pass rows (caller's stream): sized
+  // for both before either is queued
+  if (rt->n_aols || rt->n_wide) rc = ensure_z(p, rt->n_wide ? balanced_chunk(p, rt->n_wide) : 1);
+  if (rc) return rc;
+  if (!spectrum_ready) {                                  // the forward FFT ran on the caller's stream
+    spectrum_ready = p->ev_a[1];
+    HIPCHECK(hipEventRecord(spectrum_ready, M));
+  }
+  if (rt->n_poly) {
+    HIPCHECK(hipStreamWaitEvent(S0, spectrum_ready, 0));
+    rc = launch_poly_coef<T>(p, xhat, mo, 0, S0, p->side2);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(p->ev_a[0], S0));
+  }
+  if (rt->n_aols) {
+    HIPCHECK(hipStreamWaitEvent(S1, spectrum_ready, 0));
+    HIPCHECK(hipStreamWaitEvent(M, spectrum_ready, 0));   // (its rows read the Nyquist bin of the spectrum)
+  }
+  if (rt->n_ols) {                                        // block spectra queued by cwt_transform on side stream 1
+    HIPCHECK(hipStreamWaitEvent(M, p->ev_b[0], 0));
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0);
+    if (rc) return rc;
+  }
+  if (rt->n_aols) {        // band-passed signal + block spectra on side stream 1, the rows on the caller's stream
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
+    if (rc) return rc;
+  }
+  if (rt->n_ols) {
+    HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
+    if (rc) return rc;
+  }
+  if (rt->n_wide) {
+    HIPCHECK(hipStreamWaitEvent(M, spectrum_ready, 0));
+    rc = launch_wide_rows<T>(p, xhat_dev, mo, W, ldw, ncols);
+    if (rc) return rc;
+  }
+  if (rt->n_poly) {
+    HIPCHECK(hipStreamWaitEvent(M, p->ev_a[0], 0));
+    const int nchunks = int(rt->poly_chunks.size());
+    for (int c = 0; c < nchunks && !rc; ++c) {            // chunk c's rows, then chunk c + 1's coefficients
+      rc = launch_poly_rows<T>(p, c, W, ldw, ncols, M);
+      if (!rc && c + 1 < nchunks) rc = launch_poly_coef<T>(p, xhat, mo, c + 1, M, nullptr);
+    }
+  }
+  return rc;
 }
 
 // Restores the plan's stream when a scope that redirected launches to a side stream is left on any path.
@@ -608,6 +718,8 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
     if (rc) return rc;
   }
+  if (serial_schedule(p, ols_early))
+    return rows_launch_serial<T>(p, xhat_dev, mo, W_dev, ldw, ncols, p->spectrum_ready);
   if (side_narrow || ols_side) HIPCHECK(hipEventRecord(p->ev_fork, p->stream));
   if (side_narrow) HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));   // starts after the spectrum exists
   if (ols_side) {
@@ -633,29 +745,8 @@ int rows_launch(cwt_plan* p, const void* xhat_dev, const Mother& mo, int nrows, 
     HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));
   }
   if (p->rt->n_wide) {                 // two-pass rows, chunk by chunk on the plan's stream (one intermediate buffer)
-    const int logK = two_pass_logk(p), logR = logN - logK;
-    const int chunk = balanced_chunk(p, p->rt->n_wide);
-    const int nchunks = (p->rt->n_wide + chunk - 1) / chunk;
-    rc = ensure_z(p, chunk);
+    rc = launch_wide_rows<T>(p, xhat_dev, mo, W, ldw, ncols);
     if (rc) return rc;
-    cplx<T>* Z = static_cast<cplx<T>*>(p->Z);
-    for (int c = 0; c < nchunks; ++c) {
-      const int first = c * chunk, cnt = std::min(chunk, p->rt->n_wide - first);
-      const RowDesc* rows = p->rt->rows_dev + p->rt->wide_first + first;
-      rc = timed_launch(p, KC_PASS_A, [&] {
-        if (try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rows, cnt, mo, 0L, 0L, Z, p->stream)) return;
-        hipLaunchKernelGGL((k_pass_a<T, IN_SPECTRUM>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
-                           xhat_dev, rows, mo, tw_table<T>(p, logR), twn_of<T>(p), logN, logK, logP - logR, 0L, 0L, Z);
-      });
-      if (rc) return rc;
-      rc = timed_launch(p, KC_PASS_B, [&] {
-        if (try_pass_b_ct<T, false>(p, logK, rows, cnt, W, ldw, ncols, Z, p->stream)) return;
-        hipLaunchKernelGGL((k_pass_b<T, false>), dim3(1u << (logN - logP), cnt), dim3(threads), lds, p->stream,
-                           static_cast<const cplx<T>*>(Z), rows, tw_table<T>(p, logK), twn_of<T>(p), logN, logK,
-                           logP - logK, W, long(ldw), long(ncols));
-      });
-      if (rc) return rc;
-    }
   }
   if (p->rt->n_aols) {                 // after the two-pass chain: both use the intermediate buffer
     rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, p->stream);
@@ -805,8 +896,9 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
-  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1]);     // (the rows follow in rows_launch, behind the coefficients of the
-  if (rc) return rc;                                    // polynomial rows)
+  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->ev_b[0]);     // (the rows follow in rows_launch)
+  if (rc) return rc;
+  HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));      // serial schedule: all block spectra exist (the other one records it again behind the rows)
   (void)W_dev; (void)ldw; (void)ncols;
   p->ols_launched = 1;
   return CWT_OK;

@@ -95,6 +95,7 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
+  int coef_small = 1;      // interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 split in 2 / 4)
   int poly_chunk_mb = 96;  // coefficient planes computed and consumed per chunk of polynomial rows (MiB; 0 = all rows at once)
   int host_direct = 1;     // cwt_execute_host, transforms that fit one workgroup: the kernels read the signal from / write W into page-locked host memory
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
@@ -102,6 +103,9 @@ struct cwt_plan {
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_zc = 1;         // Paul rows not clipped at Nyquist on the band-passed signal too, their profile continued through f = 0
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
+  int serial_rows = 1;     // long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
+                           // other, the preparation on the side streams (rows_launch_serial); 2 = the forward FFT on a side stream too
+  hipEvent_t spectrum_ready = nullptr;   // (transient) set by cwt_transform when the forward FFT ran on side stream 0
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
@@ -181,6 +185,7 @@ struct cwt_plan {
       int row_first = 0, nrows = 0, max_logk = 8;   // rows relative to poly_first
       cwt::PolyClasses cls{};                            // (row_first of a class relative to the chunk)
       long wgs[3] = {0, 0, 0};                      // workgroups of the k_poly_coef launches on 4096- / 8192- / 16384-point tiles
+      long wgs_all = 0;                             // ... of the single launch of k_poly_coef_all (option "coef_small")
     };
     std::vector<PolyChunk> poly_chunks;
     long poly_coef_elems = 0, poly_band_elems = 0;
@@ -262,6 +267,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
                     const int* tab_nband = nullptr, int rows_per_signal = 0, int64_t tab_ld = -1,
                     int64_t ols_ncols = 0, int64_t out_ncols = 0);
 void set_split(cwt_plan* p);
+bool serial_schedule(const cwt_plan* p, bool ols_early);
 int chunk_rows_of(const cwt_plan* p);
 int balanced_chunk(const cwt_plan* p, int nrows);
 int two_pass_logk(const cwt_plan* p);

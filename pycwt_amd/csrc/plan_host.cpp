@@ -1099,7 +1099,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       PolyClasses& pc = ch.cls;
       if (pc.n == 0 || pc.c[pc.n - 1].logK != r.logK) {
         if (pc.n == POLY_MAX_CLASSES) return fail(CWT_EINVAL, "too many polynomial-row classes");
-        pc.c[pc.n++] = PolyClass{r.logK, int(i) - ch.row_first, 0, 0, 0};
+        pc.c[pc.n++] = PolyClass{r.logK, int(i) - ch.row_first, 0, 0, 0, 0};
       }
       PolyClass& c = pc.c[pc.n - 1];
       c.nrows++;
@@ -1113,12 +1113,25 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         long& wg = ch.wgs[tile - 12];
         c.wg_first = int(wg);
         wg += (long(c.nrows) * c.ndeg + tb - 1) / tb;
+        // the single launch on 4096-point tiles: K' > 4096 takes K' / 4096 workgroups per job, in groups of 8 jobs
+        const long jobs = long(c.nrows) * c.ndeg, s = c.logK > 12 ? 1L << (c.logK - 12) : 1;
+        c.wg_first1 = int(ch.wgs_all);
+        ch.wgs_all += c.logK > 12 ? ((jobs + 7) / 8) * 8 * s : (((jobs << c.logK) + 4095) / 4096 + 7) / 8 * 8;
       }
     p->rt->poly_coef_elems = off;
     p->rt->poly_band_elems = boff;
     p->rt->table.insert(p->rt->table.end(), poly_rows.begin(), poly_rows.end());
   }
   return CWT_OK;
+}
+
+// Does the current row table take the serial schedule of rows_launch_serial (launch_impl.hpp)?  Long transforms whose rows are
+// polynomial rows plus any of overlap-save / band-passed / two-pass rows, one signal, not while profiling (every timed kernel
+// runs alone on the plan's stream then).
+bool serial_schedule(const cwt_plan* p, bool ols_early) {
+  const auto* rt = p->rt;
+  return p->serial_rows && p->overlap_narrow && !p->profile && p->logN >= 18 && rt->n_poly && !rt->n_narrow && !rt->n_small &&
+         (rt->n_wide || rt->n_ols || rt->n_aols) && (!rt->n_ols || ols_early) && rt->aols_nbatch == 1 && rt->ols_nbatch == 1;
 }
 
 // log2 of the row length K of the two-pass factorisation N = R*K

@@ -289,3 +289,22 @@ def test_complex64_overlap_save_rows_as_block_pairs(emu_library, kind, param):
         per_row, _ = row_errors(W[mine], ref)
         assert per_row.max() < TOL[32], (n0, per_row.argmax(), per_row.max(), classes[mine[per_row.argmax()]])
     assert {"ols", "aols"} <= seen
+
+
+@pytest.mark.parametrize("logn,scales", [(20, [230.0, 300.0, 400.0]), (19, [150.0, 200.0, 260.0])])
+def test_interval_coefficients_of_long_transforms_on_small_workgroups(emu_library, logn, scales):
+    """K' = 8192 / 16384 interval coefficients as 2 / 4 decimated 4096-point transforms per job on 256-thread workgroups
+    (k_poly_coef_all, option coef_small, the default) against the oracle and against the one-workgroup-per-job tiles."""
+    N = 1 << logn
+    n0 = N - 77
+    x = np.random.default_rng(5).standard_normal(n0)
+    m = orc.Mother(orc.MORLET, 6)
+    sj = np.array(scales)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :n0]
+    W, split, classes = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"coef_small": 1}, with_signal=False)
+    big = [i for i, c in enumerate(classes) if c.startswith("poly/K%d/" % (N >> 6)) or c.startswith("poly/K%d/" % (N >> 7))]
+    assert big and any(c.startswith("poly/K%d/" % (N >> 6)) for c in classes), classes
+    assert row_errors(W, ref)[0].max() < 3 * TOL[64]
+    W0, _, classes0 = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"coef_small": 0}, with_signal=False)
+    assert classes0 == classes
+    assert row_errors(W[big], W0[big])[0].max() < 3 * TOL[64]
