@@ -202,6 +202,13 @@ int cwt_device_count(int* count) {
   return CWT_OK;
 }
 
+// Events that only order streams (fork / join of the side streams): no timestamps.  CWT_EVENT_TIMING=1 creates them with
+// timestamps as before round 6 (A/B of the hand-over latency).
+static hipError_t order_event(hipEvent_t* e) {
+  static const bool timing = [] { const char* v = std::getenv("CWT_EVENT_TIMING"); return v && std::atoi(v) != 0; }();
+  return timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+
 int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, int max_rows) {
   if (!plan) return fail(CWT_EINVAL, "plan is NULL");
   *plan = nullptr;
@@ -230,12 +237,12 @@ int cwt_plan_create(cwt_plan** plan, int device, int64_t nfft, int precision, in
   if (!rc) rc = precision == 64 ? set_func_attrs<double>() : set_func_attrs<float>();
   for (int i = 0; i < 2 && !rc; ++i) {
     if (create_side_stream(&p->side[i]) != hipSuccess ||
-        hipEventCreate(&p->ev_a[i]) != hipSuccess || hipEventCreate(&p->ev_b[i]) != hipSuccess)
+        order_event(&p->ev_a[i]) != hipSuccess || order_event(&p->ev_b[i]) != hipSuccess)
       rc = fail(CWT_EHIP, "cannot create side streams/events");
   }
-  if (!rc && hipEventCreate(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && hipEventCreate(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
-  if (!rc && (create_side_stream(&p->side2) != hipSuccess || hipEventCreate(&p->ev_big) != hipSuccess))
+  if (!rc && order_event(&p->ev_fork) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  if (!rc && order_event(&p->ev_ols) != hipSuccess) rc = fail(CWT_EHIP, "cannot create event");
+  if (!rc && (create_side_stream(&p->side2) != hipSuccess || order_event(&p->ev_big) != hipSuccess))
     rc = fail(CWT_EHIP, "cannot create side streams/events");
   p->narrow_mix = precision == 64;
   p->ols_big = precision == 32;                   // measured: +2.5 % (fp32 DOG), +-0 at one GPU and -3 % per rank of 8 in fp64
@@ -356,6 +363,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_small_max_halo") { if (value < 0 || value > 1024 || (value & 63)) return fail(CWT_EINVAL, "ols_small_max_halo: multiple of 64 in [0, 1024]"); p->ols_small_max_halo = int(value); }
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
+  else if (k == "aols_small_b") p->aols_small_b = value != 0;
   else if (k == "serial_rows") { if (value < 0 || value > 2) return fail(CWT_EINVAL, "serial_rows: 0, 1 or 2"); p->serial_rows = int(value); }
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
@@ -529,6 +537,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
       return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                            : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
     if (p->rt->n_ols && p->ols_early && !p->profile) {
+      p->ols_first_on_main = p->serial_rows == 2 && serial_schedule(p, true) && p->rt->ols_grp[0].nrows > 0;
       r = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
                         : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
       if (r) return r;
@@ -552,6 +561,7 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
     if (!r) r = p->prec == 64 ? rows_impl<double>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                               : rows_impl<float>(p, xhat_dev, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
     p->ols_launched = 0;
+    p->ols_first_on_main = 0;
     p->spectrum_ready = nullptr;
     return r;
   };

@@ -31,6 +31,11 @@
 #ifndef CWT_OLS_PAD_LOGTB
 #define CWT_OLS_PAD_LOGTB 2
 #endif
+// Overlap-save block transforms with K >= 256: the per-residue rotation from a table in LDS, the per-thread factor and the
+// wrap of the aliased index folded into stage 1 (ols_band_body).  0 = the running product with the wrap (A/B).
+#ifndef CWT_OLS_ROT_TABLE
+#define CWT_OLS_ROT_TABLE 1
+#endif
 #ifndef CWT_LB_NARROW_F64
 #define CWT_LB_NARROW_F64 4
 #endif

@@ -198,30 +198,62 @@ __device__ __forceinline__ void ols_band_body(const cplx<T>* __restrict__ xb, co
     const int q = int(threadIdx.x) + i * BD;
     if (q < K) ytile[q] = ols_apply<T>(yv[i], gv[i], rd.k_lo + ((q - rd.k_lo) & (K - 1)));
   }
-  __syncthreads();
   const int sh = logN - LOGP - logx;
   const unsigned pm = (1u << (LOGP + logx)) - 1u;
-  const cplx<T> step = twn(((unsigned(NT) * r) & pm) << sh);
-  const cplx<T> rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
   const int c0 = ((0 - rd.k_lo) & (K - 1)) >> (LOGK - 4);               // (-k_lo mod K) / NT, k_lo = 0 mod NT
-  const int ew = 16 - c0;                                               // uniform: first slot after the wrap
-  cplx<T> cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
   T re[16], im[16];
+  if constexpr (LOGK >= 8 && CWT_OLS_ROT_TABLE) {
+    // Slot e' <- bin k_lo + j + e' NT, which sits at FFT position j + ((e' - c0) mod 16) NT: the 16 inputs of a thread in
+    // the cyclic order that makes their bins consecutive -- no wrap inside the thread.  Its rotation is
+    //   e^{2 pi i (k_lo + j + e' NT) r / P_b} = A(j, r) S(r)^e',   S^e' = e^{2 pi i r e' / (16 M)}  (M = P_b / K residues)
+    // S^e' comes from a table of 16 x TB entries in LDS (one look-up per thread to build it), A is left out here: stage 0 is
+    // linear in a thread's inputs, its outputs go to 16 other threads, and what arrives in thread j', slot m, came from
+    // thread (j' >> 4) + m NT/16 -- so stage 1 applies A together with its own twiddles as start (w sigma)^m, and the cyclic
+    // order as the constant W16^(c ew) of its output index c = j' mod 16 (Fft::run_pre).  16 complex multiplications per
+    // thread here instead of 32 + the 15 of the wrap.
+    constexpr int TB = 1 << LOGTB;
+    cplx<T>* ttab = ytile + K;
+    if (int(threadIdx.x) < 16 * TB) {
+      const unsigned e = threadIdx.x >> LOGTB, rr = (g << LOGTB) + (threadIdx.x & (TB - 1));
+      ttab[threadIdx.x] = (tw_all + ((16u << (LOGTB + logx)) - 2u))[rr * e];
+    }
+    __syncthreads();
+    const cplx<T> a0 = twn(((unsigned(rd.k_lo + (f.j >> 4)) * r) & pm) << sh);
+    const cplx<T> sigma = twn(((unsigned(NT >> 4) * r) & pm) << sh);
+    const int ew = (16 - c0) & 15;
+    const cplx<T> phi = (tw_all + 14)[((f.j & 15) * ew) & 15];           // W16^(c ew)
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const cplx<T> y = ytile[f.j + e * NT];
-    re[e] = y.x * cur.x - y.y * cur.y;
-    im[e] = y.x * cur.y + y.y * cur.x;
-    if (e < 15) cur = cmul<T>(cur, step);
-    if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
+    for (int e = 0; e < 16; ++e) {
+      const cplx<T> y = ytile[f.j + (((e + ew) & 15) << (LOGK - 4))];
+      const cplx<T> tt = ttab[(e << LOGTB) + f.t];
+      re[e] = y.x * tt.x - y.y * tt.y;
+      im[e] = y.x * tt.y + y.y * tt.x;
+    }
+    __syncthreads();                                       // the band tile aliases the exchange buffer
+    f.run_pre(re, im, lds, tw_all + (K - 2), cmul<T>(phi, a0), sigma);
+  } else {
+    __syncthreads();
+    const cplx<T> step = twn(((unsigned(NT) * r) & pm) << sh);
+    const cplx<T> rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
+    const int ew = 16 - c0;                                               // uniform: first slot after the wrap
+    cplx<T> cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const cplx<T> y = ytile[f.j + e * NT];
+      re[e] = y.x * cur.x - y.y * cur.y;
+      im[e] = y.x * cur.y + y.y * cur.x;
+      if (e < 15) cur = cmul<T>(cur, step);
+      if (e + 1 == ew) cur = cmul<T>(cur, rhoc);                          // uniform branch
+    }
+    __syncthreads();                                       // the band tile aliases the exchange buffer
+    f.run(re, im, lds, tw_all + (K - 2));
   }
-  __syncthreads();                                       // the band tile aliases the exchange buffer
-  f.run(re, im, lds, tw_all + (K - 2));
+  const unsigned nlim_u = nlim > 0 ? unsigned(nlim) : 0u;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     // n_local = (P_b / K) (j + e NT) + r; with P_b = P this is thread + e P/16
     const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
-    if (nl >= 0 && nl < nlim) store_w<T>(wout + nl, re[e], im[e]);
+    if (unsigned(nl) < nlim_u) store_w<T>(wout + nl, re[e], im[e]);
   }
 }
 

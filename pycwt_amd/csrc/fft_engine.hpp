@@ -212,6 +212,22 @@ __device__ __forceinline__ void twiddle_chain(T (&re)[R], T (&im)[R], S wr, S wi
   }
 }
 
+// element m *= start * ratio^m, m = 0..R-1 (a stage's twiddles with a per-thread factor and a per-slot ratio folded in)
+template <typename T, int R, typename S>
+__device__ __forceinline__ void twiddle_chain_from(T (&re)[R], T (&im)[R], S pr, S pi, S wr, S wi) {
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const T x = re[m], y = im[m];
+    re[m] = x * pr - y * pi;
+    im[m] = x * pi + y * pr;
+    if (m + 1 < R) {
+      const S nr = pr * wr - pi * wi;
+      pi = pr * wi + pi * wr;
+      pr = nr;
+    }
+  }
+}
+
 // Stockham exchange of one real plane: slot n goes to position base + n*Ns,
 // slot e comes back from position j + e*NT.
 template <typename T, bool PLANES>
@@ -370,6 +386,32 @@ struct Fft {
     const int wphys = phys(((j - k) << 4) + k);
     exchange<LOGNS>(re, lds, wphys, rphys);
     exchange<LOGNS>(im, lds, wphys, rphys);
+  }
+
+  // As run(), for callers that (i) hand the 16 inputs of stage 0 over in the cyclic slot order (e + ew) mod 16 and (ii) left a
+  // factor A(source thread) = A0 sigma^(16 j_src) ... out of them -- see ols_band_body: stage 1 then multiplies slot m by
+  // start (w sigma)^m instead of w^m, with start = W16^(c ew) A0 of THIS thread (c = j mod 16).  Needs two full stages.
+  __device__ __forceinline__ void run_pre(T (&re)[16], T (&im)[16], T* lds, const cplx<sc_t<T>>* __restrict__ tw,
+                                          cplx<sc_t<T>> start, cplx<sc_t<T>> sigma) const {
+    static_assert(NFULL >= 2, "run_pre: L >= 256");
+    const int rphys = phys(j);
+    full_stage<0>(re, im, lds, tw, rphys);
+    {
+      const int k = j & 15;
+      const cplx<sc_t<T>> w = stage_tw<sc_t<T>>(tw, k << (LOGL - 8));
+      const cplx<sc_t<T>> ratio = cmul<sc_t<T>>(w, sigma);
+      twiddle_chain_from<T, 16>(re, im, start.x, start.y, ratio.x, ratio.y);
+      bfly16<T>(re, im);
+      if constexpr (!(NFULL == 2 && REM == 0)) {
+        const int wphys = phys(((j - k) << 4) + k);
+        exchange<4>(re, lds, wphys, rphys);
+        exchange<4>(im, lds, wphys, rphys);
+      }
+    }
+    if constexpr (NFULL >= 3) full_stage<2>(re, im, lds, tw, rphys);
+    if constexpr (REM == 1) partial_stage<T, 2>(re, im, j, LOGL, 4 * NFULL, tw);
+    if constexpr (REM == 2) partial_stage<T, 4>(re, im, j, LOGL, 4 * NFULL, tw);
+    if constexpr (REM == 3) partial_stage<T, 8>(re, im, j, LOGL, 4 * NFULL, tw);
   }
 
   // in: slot e = x[j + e*NT]; out: slot e = X[j + e*NT].  lds: LDS_ELEMS reals.

@@ -338,13 +338,13 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
   }, st);
 }
 template <typename T>
-int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, hipEvent_t after_first = nullptr) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, hipEvent_t after_first = nullptr, int g_only = -1) {
   int rc = CWT_OK;
   {
     for (int g = 0; g < 2 && !rc; ++g) {
       if (g == 1 && after_first) HIPCHECK(hipEventRecord(after_first, st));     // the half-size tiles' spectra exist
       const auto& G = p->rt->ols_grp[g];
-      if (!G.nrows) continue;
+      if (!G.nrows || (g_only >= 0 && g != g_only)) continue;
       for (int d = 0; d < 3 && !rc; ++d) {
         if (!G.fwd_blocks[d]) continue;
         switch (G.logp + d) {                                   // log2 of the block length
@@ -393,11 +393,11 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
 
 // Rows clipped at Nyquist (k_aols_*): band-passed complex signal x_M = IFFT_N(xhat mask) through the two-pass kernels
 // (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
-// st_rows != nullptr (one signal only): the band-passed signal and its block spectra on st, `ready` recorded behind them,
+// ready != nullptr (one signal only): the band-passed signal and its block spectra on st, `ready` recorded behind them,
 // the rows on st_rows behind that event.
 template <typename T, int LOGP>
 int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
-                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
+                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {      // (ready == nullptr: everything on st; the caller's stream may be the null stream)
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
@@ -426,7 +426,10 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
     if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
-      ok = try_pass_b_ct<T, false>(p, logK, nullptr, cnt, xm, p->N, p->N, Z, st);
+      // (beside the overlap-save rows the default tile's 512-thread workgroups do not find a CU before those drain: 170-250 us
+      // for 16; 256-thread workgroups get their turn)
+      if (p->aols_small_b && ready && logK == 10 && default_logp<T>() == 13 && p->use_ct) { launch_pass_b_ct_lp<T, 10, 12, false>(p, nullptr, cnt, xm, p->N, p->N, Z, st); ok = true; }
+      else ok = try_pass_b_ct<T, false>(p, logK, nullptr, cnt, xm, p->N, p->N, Z, st);
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
     if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
@@ -434,7 +437,7 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
     hipStream_t sr = st;
-    if (!rc && st_rows && nb == 1) {
+    if (!rc && ready && nb == 1) {
       HIPCHECK(hipEventRecord(ready, st));
       HIPCHECK(hipStreamWaitEvent(st_rows, ready, 0));
       sr = st_rows;
@@ -483,7 +486,7 @@ int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int6
     case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, st_rows, ready); break;
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
-  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, st_rows ? st_rows : st);
+  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, ready ? st_rows : st);
   return rc;
 }
 
@@ -614,22 +617,20 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_a[0], S0));
   }
-  if (rt->n_aols) {
-    HIPCHECK(hipStreamWaitEvent(S1, spectrum_ready, 0));
-    HIPCHECK(hipStreamWaitEvent(M, spectrum_ready, 0));   // (its rows read the Nyquist bin of the spectrum)
-  }
+  if (rt->n_aols) HIPCHECK(hipStreamWaitEvent(S1, spectrum_ready, 0));   // (the rows wait for the band-passed signal, made from the spectrum)
   if (rt->n_ols) {                                        // block spectra queued by cwt_transform on side stream 1
-    HIPCHECK(hipStreamWaitEvent(M, p->ev_b[0], 0));
+    if (!p->ols_first_on_main) HIPCHECK(hipStreamWaitEvent(M, p->ev_b[0], 0));
     rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0);
     if (rc) return rc;
   }
-  if (rt->n_aols) {        // band-passed signal + block spectra on side stream 1, the rows on the caller's stream
-    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
-    if (rc) return rc;
-  }
-  if (rt->n_ols) {
+  if (rt->n_ols && rt->ols_grp[1].nrows) {
     HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
     rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
+    if (rc) return rc;
+  }
+  if (rt->n_aols) {        // band-passed signal + block spectra on side stream 1 (behind the block spectra of the signal: they have
+                           // the two overlap-save launches to get done), the rows on the caller's stream
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
     if (rc) return rc;
   }
   if (rt->n_wide) {
@@ -896,7 +897,12 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
-  rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->ev_b[0]);     // (the rows follow in rows_launch)
+  if (p->ols_first_on_main) {                           // serial_rows = 2: the first rows' spectra where the rows will follow
+    rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream, nullptr, 0);
+    if (!rc) rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], nullptr, 1);
+  } else {
+    rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->ev_b[0]);     // (the rows follow in rows_launch)
+  }
   if (rc) return rc;
   HIPCHECK(hipEventRecord(p->ev_ols, p->side[1]));      // serial schedule: all block spectra exist (the other one records it again behind the rows)
   (void)W_dev; (void)ldw; (void)ncols;

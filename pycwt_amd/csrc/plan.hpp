@@ -95,7 +95,7 @@ struct cwt_plan {
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
-  int coef_small = 1;      // interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 split in 2 / 4)
+  int coef_small = 0;      // interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 split in 2 / 4); measured slower (EXPERIMENTS R6.2)
   int poly_chunk_mb = 96;  // coefficient planes computed and consumed per chunk of polynomial rows (MiB; 0 = all rows at once)
   int host_direct = 1;     // cwt_execute_host, transforms that fit one workgroup: the kernels read the signal from / write W into page-locked host memory
   int graph = 0;           // cwt_transform: capture the launches of a repeated call (same buffers, same row table) into a
@@ -104,9 +104,12 @@ struct cwt_plan {
   int aols_zc = 1;         // Paul rows not clipped at Nyquist on the band-passed signal too, their profile continued through f = 0
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int serial_rows = 1;     // long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
-                           // other, the preparation on the side streams (rows_launch_serial); 2 = the forward FFT on a side stream too
+                           // other, the preparation on the side streams (rows_launch_serial); 2 = also the first block spectra on the
+                           // caller's stream (its rows follow at a kernel boundary) and the forward FFT on side stream 0
   hipEvent_t spectrum_ready = nullptr;   // (transient) set by cwt_transform when the forward FFT ran on side stream 0
+  int aols_small_b = 1;    // serial schedule, complex128: the band-passed signal's second pass on 4096-point tiles (256-thread workgroups)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
+  int ols_first_on_main = 0;   // (transient) serial_rows = 2: the block spectra of the half-size tiles were queued on the caller's stream
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -145,14 +146,15 @@ static hipEvent_t e0, e1;
 static const int rows = 64;
 static const size_t N = size_t(1) << 20;
 
+static int g_burst = 1;      // launches between the two events (1: a host round trip after every launch, as stream_poly3.hip times)
 template <class F> float timeit(F&& launch, size_t ncoef) {
   float tot = 0; const int reps = 8;
   for (int i = 0; i < reps + 2; ++i) {
     CK(hipEventRecord(e0));
-    launch();
+    for (int b = 0; b < g_burst; ++b) launch();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    if (i >= 2) tot += ms;
+    if (i >= 2) tot += ms / g_burst;
   }
   (void)ncoef;
   return tot / reps;
@@ -178,7 +180,48 @@ void run_persist(const char* name, int logK, int per_cu) {
   report(buf, D, logK, timeit([&] { hipLaunchKernelGGL((k_persist<D, I>), dim3(256 * per_cu), dim3(256), 2 * half * 16, 0, W, coef, logK, hi, lo, kcs, nchunks_row, unsigned(rows)); }, 0));
 }
 
-int main() {
+static void fill_tables(bool zero_tw, bool zero_coef, bool smooth_coef) {
+  std::vector<double2> h(1024), l(1024);
+  for (int i = 0; i < 1024; ++i) {
+    const double ah = 6.283185307179586 * double(i) / 1024.0, al = 6.283185307179586 * double(i) / 1048576.0;
+    h[i] = zero_tw ? make_double2(0, 0) : make_double2(cos(ah), sin(ah));
+    l[i] = zero_tw ? make_double2(0, 0) : make_double2(cos(al), sin(al));
+  }
+  CK(hipMemcpy(hi, h.data(), 1024 * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(lo, l.data(), 1024 * 16, hipMemcpyHostToDevice));
+  std::vector<double2> c(size_t(rows) * 13 * 16384);
+  unsigned s = 12345u;
+  size_t i = 0;
+  for (auto& v : c) {
+    s = s * 1664525u + 1013904223u; v.x = double(int(s)) * 4.656612873077393e-10; s = s * 1664525u + 1013904223u; v.y = double(int(s)) * 4.656612873077393e-10;
+    if (zero_coef) v = make_double2(0, 0);
+    if (smooth_coef) v = make_double2(1e-3 * double(i & 1023), 1.0);
+    ++i;
+  }
+  CK(hipMemcpy(coef, c.data(), c.size() * 16, hipMemcpyHostToDevice));
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "data") {      // what does the DATA cost?  base kernel, K' = 2^11, degree 8
+    CK(hipMalloc(&W, rows * N * 16)); CK(hipMalloc(&coef, size_t(rows) * 13 * 16384 * 16)); CK(hipMalloc(&hi, 1024 * 16)); CK(hipMalloc(&lo, 1024 * 16));
+    CK(hipMalloc(&kcs, rows * 4));
+    int k[64]; for (int i = 0; i < 64; ++i) k[i] = 1000 + 37 * i;
+    CK(hipMemcpy(kcs, k, rows * 4, hipMemcpyHostToDevice));
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int burst : {1, 10}) {
+      g_burst = burst;
+      printf("-- %d launch(es) per timed region\n", burst);
+      report("fill (hash values, store only)", 0, 0, timeit([&] { hipLaunchKernelGGL(k_fill, dim3(unsigned(N / 256), rows), dim3(256), 0, 0, W); }, 0));
+      for (int mode = 0; mode < 5; ++mode) {
+        fill_tables(mode == 1 || mode == 3, mode == 2 || mode == 3, mode == 4);
+        const char* names[5] = {"random coefficients, real carrier", "random coefficients, ZERO carrier", "ZERO coefficients, real carrier", "all zero", "smooth coefficients, real carrier"};
+        for (int logK : {8, 11, 14}) {
+          run<8, 2, 256, false, 1, true>(names[mode], logK);
+        }
+        run_persist<8, 2>(names[mode], 11, 7);
+      }
+    }
+    return 0;
+  }
   CK(hipMalloc(&W, rows * N * 16)); CK(hipMalloc(&coef, size_t(rows) * 13 * 16384 * 16)); CK(hipMalloc(&hi, 1024 * 16)); CK(hipMalloc(&lo, 1024 * 16));
   CK(hipMalloc(&kcs, rows * 4));
   {
