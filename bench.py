@@ -225,6 +225,40 @@ class Workload:
         return {"ms_per_step": ms, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9,
                 "host_enqueue_ms_per_step": self.host_enqueue_ms}
 
+    def api_timed(self, steps, warmup):
+        """The same K steps through the PUBLIC multi-GPU entry point, `pycwt_amd.parallel.cwt_sharded` (shape known to every
+        rank, `assume_finite=True`, the signal already on rank 0's device): one broadcast per call, the scale grid, the shards
+        and the output tensor made inside the call -- what a caller of the API pays, beside the bench's own loop above (which
+        double-buffers the broadcast of step i + 1 under step i)."""
+        import pycwt_amd
+        from pycwt_amd import parallel
+        rt = self.rt
+        mother = {0: pycwt_amd.Morlet, 1: pycwt_amd.Paul, 2: pycwt_amd.DOG}[self.kind](self.param)
+        s0 = 2 * self.dt / mother.flambda()
+        dj = np.log2(self.N * self.dt / s0) / (self.rows_total - 1)
+        eng = parallel.HipEngine(self.N, self.prec, self.rows_total, rt.device_index, on_torch_stream=not rt.emulate,
+                                 options=self.opts, lib=rt.lib)
+        x = self.xbuf[0] if rt.rank == 0 else None
+        group = None
+        rows_seen = [0]
+
+        def run(count):
+            for _ in range(count):
+                W, mine, *_ = parallel.cwt_sharded(x, self.dt, dj, s0, self.rows_total - 1, mother, precision=self.prec,
+                                                   device=rt.dev, engine=eng, shape=(self.N,), assume_finite=True, group=group)
+                rows_seen[0] = len(mine)
+        run(max(1, warmup))
+        rt.fence()
+        t0 = time.perf_counter()
+        run(steps)
+        host = (time.perf_counter() - t0) / steps * 1e3
+        rt.fence()
+        elapsed = rt.max_over_ranks(time.perf_counter() - t0)
+        eng.plan.close()
+        return {"ms_per_step": elapsed / steps * 1e3, "value": float(self.N) * self.rows_total / (elapsed / steps) / 1e9,
+                "host_ms_per_call": host, "rows_this_rank": rows_seen[0], "collectives_per_call": 1 if rt.use_dist else 0,
+                "entry_point": "pycwt_amd.parallel.cwt_sharded(x_dev, ..., shape=(N,), assume_finite=True)"}
+
     def prime(self, min_ms):
         """Untimed steps until at least `min_ms` of wall time have passed: brings the device from its idle clock to its
         sustained clock (DPM ramps over the first ~45 ms of work; measured with tools/clock_ramp.py: 1.23 ms per step
@@ -725,6 +759,9 @@ def compact_line(out, detail_path):
         line["icwt_ms"] = out["icwt"]["ms"]
     if "weak_scaling" in out:
         line["weak_scaling"] = out["weak_scaling"]
+    if "api" in out:                       # the same steps through pycwt_amd.parallel.cwt_sharded itself
+        line["api_ms_per_step"] = out["api"]["ms_per_step"]
+        line["api_collectives_per_call"] = out["api"]["collectives_per_call"]
     ex = out.get("extra") or {}
     short = {}
     if "c2_roundoff" in ex:
@@ -779,6 +816,8 @@ def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True):
     else:
         out = wl.timed(args.steps, args.warmup)
         out["effective_warmup_steps"] = args.warmup
+    if rt.use_dist and not args.shard and wl.kind != 1:      # (Paul: the API drops the reference's NaN rows, another workload)
+        out["api"] = wl.api_timed(args.steps, args.warmup)
     traffic = None
     if (args.live_traffic and traffic_passes and not args.emulate and not wl.sharded and not rt.use_dist and not args.shard and want_cpu
             and set(wl.opts) <= {"tolerance"} and wl.tolerance == BENCH_TOLERANCE[wl.prec]):
@@ -915,7 +954,7 @@ def main():
         weak = measure(rt, args.config, args, args.rows * world, opts, want_cpu=False)
         out["weak_scaling"] = {"value": weak["value"], "ms_per_step": weak["ms_per_step"], "rows_total": args.rows * world,
                                "rows_per_gpu": args.rows}
-    for k in ("effective_warmup_steps", "icwt", "host_enqueue_ms_per_step"):
+    for k in ("effective_warmup_steps", "icwt", "host_enqueue_ms_per_step", "api"):
         if k in head:
             out[k] = head[k]
     if single and args.config == "c2" and not args.no_extra and not opts and not args.emulate:

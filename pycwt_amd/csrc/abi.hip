@@ -364,7 +364,8 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "ols_big_min_halo") { if (value < 64 || value > 8192) return fail(CWT_EINVAL, "ols_big_min_halo in [64, 8192]"); p->ols_big_min_halo = int(value); }
   else if (k == "ols_early") p->ols_early = value != 0;
   else if (k == "aols_small_b") p->aols_small_b = value != 0;
-  else if (k == "serial_rows") { if (value < 0 || value > 2) return fail(CWT_EINVAL, "serial_rows: 0, 1 or 2"); p->serial_rows = int(value); }
+  else if (k == "fft_aside_small") p->fft_aside_small = value != 0;
+  else if (k == "serial_rows") { if (value < 0 || value > 3) return fail(CWT_EINVAL, "serial_rows: 0 ... 3"); p->serial_rows = int(value); }
   else if (k == "ols_max_halo") { if (value < 0 || value > 4096 || (value & 63)) return fail(CWT_EINVAL, "ols_max_halo: multiple of 64 in [0, 4096]"); p->ols_max_halo = int(value); }
   else if (k == "ols_fwd_weight") { if (value < 0 || value > 1000) return fail(CWT_EINVAL, "ols_fwd_weight: percent of a row, 0..1000"); p->ols_fwd_weight = double(value) / 100.0; }
   else if (k == "tolerance_neglog10") {   // integer alias of cwt_plan_set_tolerance for option sweeps: 10^-value; 0 = default
@@ -537,23 +538,25 @@ int cwt_transform(cwt_plan* p, const void* x_dev, int64_t n0, int mother, double
       return p->prec == 64 ? rows_impl<double>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0)
                            : rows_impl<float>(p, nullptr, mo, nrows, W_dev, ldw, ncols, x_dev, n0);
     if (p->rt->n_ols && p->ols_early && !p->profile) {
-      p->ols_first_on_main = p->serial_rows == 2 && serial_schedule(p, true) && p->rt->ols_grp[0].nrows > 0;
+      p->ols_first_on_main = p->serial_rows >= 2 && serial_schedule(p, true) && p->rt->ols_grp[0].nrows > 0;
       r = p->prec == 64 ? launch_ols_early<double>(p, x_dev, n0, W_dev, ldw, ncols)
                         : launch_ols_early<float>(p, x_dev, n0, W_dev, ldw, ncols);
       if (r) return r;
     }
     // serial_rows = 2: the forward FFT on side stream 0 (the bands + coefficients of the polynomial rows follow it there), so that
     // the first overlap-save rows start on the caller's stream as soon as their block spectra exist
-    const bool fft_aside = p->serial_rows == 2 && serial_schedule(p, p->ols_launched != 0);
+    const bool fft_aside = p->serial_rows >= 2 && serial_schedule(p, p->ols_launched != 0);
     hipStream_t caller = p->stream;
     if (fft_aside) {
       if (!p->ols_launched) HIPCHECK(hipEventRecord(p->ev_fork, caller));
       HIPCHECK(hipStreamWaitEvent(p->side[0], p->ev_fork, 0));
       p->stream = p->side[0];
+      p->fft_small = p->fft_aside_small;
     }
     r = p->prec == 64 ? fft_rows_impl<double, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev)
                       : fft_rows_impl<float, IN_REAL>(p, x_dev, 0, 1, n0, xhat_dev);
     p->stream = caller;
+    p->fft_small = 0;
     if (fft_aside && !r) {
       HIPCHECK(hipEventRecord(p->ev_a[1], p->side[0]));
       p->spectrum_ready = p->ev_a[1];

@@ -186,6 +186,14 @@ void launch_pass_a_ct(cwt_plan* p, const void* in, const RowDesc* rows, int cnt,
       return;
     }
   }
+  if constexpr (MODE == IN_REAL && LOGR <= LOGP - 1 && LOGR >= 8) {
+    if (p->fft_small) {      // the forward FFT beside the overlap-save rows (serial_rows = 2): half-size tiles get their turn on the CUs
+      constexpr int LP = LOGP - 1;
+      hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LP, MODE>), dim3(1u << (p->logN - LP), cnt), dim3(1 << (LP - 4)),
+                         (size_t(1) << LP) * sizeof(T), st, in, rows, mo, tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_pass_a_ct<T, LOGR, LOGP, MODE>), dim3(1u << (p->logN - LOGP), cnt),
                      dim3(1 << (LOGP - 4)), (size_t(1) << LOGP) * sizeof(T), st, in, rows, mo,
                      tw_table<T>(p, LOGR), twn_of<T>(p), p->logN, n0, in_ld, Z);
@@ -247,6 +255,9 @@ template <typename T, int LOGK, bool CONJ>
 void launch_pass_b_ct(cwt_plan* p, const RowDesc* rows, int cnt, cplx<T>* W, int64_t ldw, int64_t ncols,
                       const cplx<T>* Z, hipStream_t st) {
   constexpr int LOGP = default_logp<T>();
+  if constexpr (CONJ && LOGK <= LOGP - 1) {
+    if (p->fft_small) return launch_pass_b_ct_lp<T, LOGK, LOGP - 1, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
+  }
   launch_pass_b_ct_lp<T, LOGK, LOGP, CONJ>(p, rows, cnt, W, ldw, ncols, Z, st);
 }
 
@@ -623,13 +634,23 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0);
     if (rc) return rc;
   }
+  // serial_rows = 3: ONE wait on the caller's stream for everything the side streams prepare (each wait is a barrier packet that
+  // costs the stream 5-8 us even when its event completed long ago): side stream 1 = block spectra of the default tile, then
+  // (behind the coefficients' event) the band-passed signal, then the event the rows of that signal wait for -- which therefore
+  // come before the default tile's rows.
+  const bool one_wait = p->serial_rows == 3 && rt->n_aols && rt->n_poly;
+  if (one_wait) {
+    HIPCHECK(hipStreamWaitEvent(S1, p->ev_a[0], 0));
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
+    if (rc) return rc;
+  }
   if (rt->n_ols && rt->ols_grp[1].nrows) {
-    HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
+    if (!one_wait) HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
     rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
     if (rc) return rc;
   }
-  if (rt->n_aols) {        // band-passed signal + block spectra on side stream 1 (behind the block spectra of the signal: they have
-                           // the two overlap-save launches to get done), the rows on the caller's stream
+  if (rt->n_aols && !one_wait) {   // band-passed signal + block spectra on side stream 1 (behind the block spectra of the signal: they
+                                   // have the two overlap-save launches to get done), the rows on the caller's stream
     rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
     if (rc) return rc;
   }
@@ -639,7 +660,7 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     if (rc) return rc;
   }
   if (rt->n_poly) {
-    HIPCHECK(hipStreamWaitEvent(M, p->ev_a[0], 0));
+    if (!one_wait) HIPCHECK(hipStreamWaitEvent(M, p->ev_a[0], 0));
     const int nchunks = int(rt->poly_chunks.size());
     for (int c = 0; c < nchunks && !rc; ++c) {            // chunk c's rows, then chunk c + 1's coefficients
       rc = launch_poly_rows<T>(p, c, W, ldw, ncols, M);

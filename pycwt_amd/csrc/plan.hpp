@@ -107,7 +107,9 @@ struct cwt_plan {
                            // other, the preparation on the side streams (rows_launch_serial); 2 = also the first block spectra on the
                            // caller's stream (its rows follow at a kernel boundary) and the forward FFT on side stream 0
   hipEvent_t spectrum_ready = nullptr;   // (transient) set by cwt_transform when the forward FFT ran on side stream 0
+  int fft_aside_small = 1; // serial_rows = 2: the forward FFT (on side stream 0 beside the first overlap-save rows) on half-size tiles
   int aols_small_b = 1;    // serial schedule, complex128: the band-passed signal's second pass on 4096-point tiles (256-thread workgroups)
+  int fft_small = 0;       // (transient) set by cwt_transform while the forward FFT is queued on side stream 0 (serial_rows = 2)
   int ols_launched = 0;    // (transient) set by cwt_transform for rows_impl
   int ols_first_on_main = 0;   // (transient) serial_rows = 2: the block spectra of the half-size tiles were queued on the caller's stream
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch

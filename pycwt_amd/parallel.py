@@ -21,7 +21,7 @@ import functools
 import numpy as np
 
 from . import _hip
-from .wavelet import _check_parameter_wavelet, _coi, _device_id, _nan_rows, _next_pow2, _scale_grid
+from .wavelet import _check_parameter_wavelet, _device_id, _next_pow2
 
 
 def shard_rows(nrows: int, world: int, rank: int) -> np.ndarray:
@@ -77,15 +77,16 @@ _engines: dict = {}       # default engines of cwt_sharded, one per (length, pre
 class HipEngine:
     """Runs the hot path on this rank's GPU through libcwt_hip.so on torch's current stream."""
 
-    def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int, on_torch_stream: bool = True):
+    def __init__(self, nfft: int, precision: int, max_rows: int, device_index: int, on_torch_stream: bool = True,
+                 options=None, lib=None):
         import torch
         self.torch = torch
-        if not on_torch_stream and _hip.load().backend().startswith("hip"):
+        if not on_torch_stream and (lib or _hip.load()).backend().startswith("hip"):
             # tensors that live on the host would hand host pointers to the kernels: a GPU memory fault, not an error
             # (on_torch_stream=False is for the test suite's CPU emulation of the library)
             raise RuntimeError("HipEngine needs tensors on a GPU and torch sees none (torch.cuda.is_available() is False: "
                                "was another HIP runtime loaded before torch was imported?)")
-        self.plan = _hip.Plan(nfft, precision, max_rows=max_rows, device=device_index)
+        self.plan = _hip.Plan(nfft, precision, max_rows=max_rows, device=device_index, lib=lib, options=options)
         if on_torch_stream:               # tensors that live on a GPU: queue behind torch's work on its stream
             self.plan.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
 
@@ -123,9 +124,27 @@ class HipEngine:
         self.plan.icwt_reduce(W.data_ptr(), W.shape[1], W.shape[1], sj, 1.0, out.data_ptr())
 
 
+_shard_cache: dict = {}   # (engine, mother, grid, world, partition) -> this rank's rows: the classification of a grid is host work
+
+
+def _broadcast_shape(signal, rank, src, world, group, device, dist, torch):
+    """The signal's shape on every rank: ONE small tensor broadcast (3 x int64), only when the callers did not pass `shape=`."""
+    meta = torch.zeros(3, dtype=torch.int64, device=device)
+    if rank == src:
+        shp = tuple(signal.shape) if hasattr(signal, "shape") else np.shape(signal)
+        meta[0] = len(shp)
+        for i, v in enumerate(shp):
+            meta[1 + i] = int(v)
+    if world > 1:
+        dist.broadcast(meta, src=src, group=group)
+    m = [int(v) for v in meta.tolist()]
+    return tuple(m[1:1 + m[0]])
+
+
 def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None, *, group=None,
-                precision=64, device=None, engine=None, src=0, partition="balanced"):
-    """Scale-sharded `cwt`.  Call on every rank of `group`; only rank `src` needs `signal`.
+                precision=64, device=None, engine=None, src=0, partition="balanced", shape=None, assume_finite=False):
+    """Scale-sharded `cwt`.  Call on every rank of `group`; only rank `src` needs `signal` (a sequence / NumPy array, or a
+    torch tensor that already lives on this rank's device: no host copy then).
 
     `signal` may be 2-D (batch x n0): then every rank transforms all signals for its scales and
     `W_local` is (batch, len(rows_local), n0).
@@ -133,7 +152,14 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     Returns `(W_local, rows_local, sj, freqs, coi)`: `W_local` is a device tensor
     (len(rows_local) x n0, complex) holding rows `rows_local` of the full transform; `sj`, `freqs`,
     `coi` describe the full transform exactly as `pycwt.cwt` returns them (after the Paul NaN-row
-    rule).  One broadcast of the signal, no other collective.
+    rule; read-only views of cached arrays: copy before writing).
+
+    Collectives: ONE broadcast of the signal -- the exchange of the path -- when every rank passes `shape=` (the signal's
+    shape, `(n0,)` or `(batch, n0)`); without it one more broadcast of three integers tells the other ranks.  No host
+    synchronisation when `assume_finite=True`: by default the broadcast signal is checked for NaN / inf on the device and
+    the answer read back (a NaN sample makes every row NaN in the reference, wavelet.py:91, :111-115; the block-wise row
+    forms would confine it, so such signals take the spectrum-only entry points) -- a device-to-host round trip that costs
+    about as much as a rank's share of the transform at 8 GPUs.
 
     `rows_local` is a contiguous run of scales of about equal estimated cost (`partition="balanced"`, one signal,
     an engine that can classify the whole grid) or `rank, rank + world, ...` (`partition="interleaved"`, batches of
@@ -143,6 +169,7 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     """
     import torch
     import torch.distributed as dist
+    from .wavelet import _geometry
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -152,28 +179,28 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
-    meta = [tuple(np.shape(signal)) if rank == src else None]
-    if world > 1:
-        dist.broadcast_object_list(meta, src=src, group=group)
-    shape = tuple(int(v) for v in meta[0])           # (n0,) or (batch, n0): BASELINE config 4
+    if shape is None:
+        shape = _broadcast_shape(signal, rank, src, world, group, device, dist, torch)
+    shape = tuple(int(v) for v in shape)             # (n0,) or (batch, n0): BASELINE config 4
     n0 = shape[-1]
-    x = torch.empty(shape, dtype=real_t, device=device)
-    if rank == src:
-        x.copy_(torch.as_tensor(np.asarray(signal), dtype=real_t))
+    if rank == src and torch.is_tensor(signal) and signal.device == device and signal.dtype == real_t and tuple(signal.shape) == shape \
+            and signal.is_contiguous():
+        x = signal                                   # already where the kernels read it
+    else:
+        x = torch.empty(shape, dtype=real_t, device=device)
+        if rank == src:
+            x.copy_(signal if torch.is_tensor(signal) else torch.as_tensor(np.asarray(signal), dtype=real_t))
     if world > 1:
         dist.broadcast(x, src=src, group=group)            # the one exchange of the path
 
-    # host scalars exactly as wavelet.py:75-88 / :111-115 / :120-121
-    sj, freqs = _scale_grid(mother, n0, dt, dj, s0, J, freqs)
-    N = _next_pow2(n0)
-    bad = _nan_rows(mother, sj, N, dt)
+    # host scalars exactly as wavelet.py:75-88 / :111-115 / :120-121 (cached per grid: they do not depend on the samples)
+    N, sj, freqs, coi, _, bad = _geometry(mother, n0, dt, dj, s0, J, freqs, True)
     # a NaN / inf sample makes every row NaN in the reference (wavelet.py:91), which then keeps all rows (:111-115); the
     # block-wise rows of cwt_transform would confine the damage, so such signals go through the spectrum-only entry points
     # (as pycwt_amd.cwt does).  Every rank holds the broadcast signal and decides alike.
-    finite = bool(torch.isfinite(x).all().item())
-    if bad.any() and not bad.all() and finite:
+    finite = True if assume_finite else bool(torch.isfinite(x).all().item())
+    if bad is not None and not bad.all() and finite:
         sj, freqs = sj[~bad], np.asarray(freqs)[~bad]
-    coi = _coi(mother, n0, dt)
 
     kind, param = _device_id(mother)
     nbatch = shape[0] if len(shape) == 2 else 1
@@ -188,8 +215,20 @@ def cwt_sharded(signal, dt, dj=1 / 12, s0=-1, J=-1, wavelet="morlet", freqs=None
     # balanced shards need the classification of the WHOLE grid: an engine sized for its own share cannot give it
     can_classify = hasattr(engine, "classify") and getattr(getattr(engine, "plan", None), "max_rows", sj.size) >= sj.size
     if partition == "balanced" and nbatch == 1 and world > 1 and can_classify:
-        mine = (engine.plan.balanced_shards(kind, param, dt, sj, n0, world)[rank] if hasattr(engine, "plan")
-                else balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision, N)[rank])
+        ckey = None
+        try:
+            ckey = (id(engine), kind, param, n0, dt, sj.tobytes(), world, rank,
+                    getattr(getattr(engine, "plan", None), "tolerance", lambda: 0)())
+            mine = _shard_cache.get(ckey)
+        except TypeError:
+            mine = None
+        if mine is None:
+            mine = (engine.plan.balanced_shards(kind, param, dt, sj, n0, world)[rank] if hasattr(engine, "plan")
+                    else balanced_shards(engine.classify(kind, param, dt, sj, n0), world, precision, N)[rank])
+            if ckey is not None:
+                if len(_shard_cache) >= 64:
+                    _shard_cache.clear()
+                _shard_cache[ckey] = mine
     else:
         mine = shard_rows(sj.size, world, rank)
     W = torch.empty(shape[:-1] + (mine.size, n0), dtype=cplx_t, device=device)

@@ -69,6 +69,10 @@ def test_multi_rank_launch_as_the_driver_does(emu_library, world, tmp_path):
     assert d["weak_scaling"]["rows_total"] == 12 * world and d["weak_scaling"]["rows_per_gpu"] == 12
     assert "parity" not in d and "cpu_baseline" not in d          # rank 0 at N = 1 only
     assert d["value"] > 0 and d["weak_scaling"]["value"] > 0
+    # the same steps through the public entry point (pycwt_amd.parallel.cwt_sharded): timed, one collective per call
+    assert d["api_ms_per_step"] > 0 and d["api_collectives_per_call"] == 1
+    full = json.loads((tmp_path / "d.json").read_text())
+    assert full["api"]["rows_this_rank"] >= 1 and "cwt_sharded" in full["api"]["entry_point"]
 
 
 def test_compact_line_of_a_full_default_run_stays_small():

@@ -105,6 +105,33 @@ def _kernel_worker(rank, world, port, tmpdir):
     assert list(mine2) == list(range(rank, len(sj), world))
     W3, mine3, *_ = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu)     # second call: cached engine
     assert list(mine3) == list(mine) and len(parallel._engines) == 1
+    # the call is as cheap as its kernels: with the shape known to every rank EXACTLY ONE collective (the broadcast of the
+    # signal) and no other traffic; without it one more broadcast (three integers), never an object broadcast
+    import collections
+    counts = collections.Counter()
+    names = ("broadcast", "broadcast_object_list", "all_reduce", "reduce", "all_gather", "all_gather_object", "gather", "scatter",
+             "barrier", "send", "recv", "isend", "irecv", "all_to_all", "reduce_scatter")
+    keep = {n: getattr(dist, n) for n in names}
+
+    def counted(n):
+        def call(*a, **k):
+            counts[n] += 1
+            return keep[n](*a, **k)
+        return call
+    for n in names:
+        setattr(dist, n, counted(n))
+    try:
+        W4, mine4, *_ = parallel.cwt_sharded(x, 0.5, 1 / 4, -1, -1, "morlet", device=cpu, shape=(5000,), assume_finite=True)
+        assert dict(counts) == {"broadcast": 1}, dict(counts)
+        counts.clear()
+        xt = torch.from_numpy(x) if rank == 0 else None                  # a tensor that is already on the device: used as it is
+        W5, mine5, *_ = parallel.cwt_sharded(xt, 0.5, 1 / 4, -1, -1, "morlet", device=cpu, assume_finite=True)
+        assert dict(counts) == {"broadcast": 2}, dict(counts)
+    finally:
+        for n in names:
+            setattr(dist, n, keep[n])
+    assert list(mine4) == list(mine) and list(mine5) == list(mine)
+    assert np.array_equal(W4.numpy(), W.numpy()) and np.array_equal(W5.numpy(), W.numpy())
     X = np.random.default_rng(7).standard_normal((3, 700)) if rank == 0 else None
     Wb, mineb, sjb, _, _ = parallel.cwt_sharded(X, 1.0, 1 / 2, -1, -1, "dog", device=cpu, precision=32)
     np.savez(os.path.join(tmpdir, f"k{rank}.npz"), W=W.numpy(), mine=mine, sj=sj, iw=np.zeros(0) if iw is None else iw,
