@@ -759,6 +759,9 @@ def compact_line(out, detail_path):
         line["icwt_ms"] = out["icwt"]["ms"]
     if "weak_scaling" in out:
         line["weak_scaling"] = out["weak_scaling"]
+    if "build" in out and "id" in out["build"]:
+        line["build_id"] = out["build"]["id"]
+        line["build_matches_tree"] = out["build"]["matches_tree"]
     if "api" in out:                       # the same steps through pycwt_amd.parallel.cwt_sharded itself
         line["api_ms_per_step"] = out["api"]["ms_per_step"]
         line["api_collectives_per_call"] = out["api"]["collectives_per_call"]
@@ -940,6 +943,14 @@ def main():
                    **({"signals_in_flight": args.pipeline} if args.pipeline > 1 else {})},
         "roofline": head["roofline"],
     }
+    try:       # which binary was measured: the id embedded in the loaded library against the id of this tree's sources
+        from pycwt_amd import _build
+        tree = _build.source_id() if all(os.path.exists(d) for d in _build.DEPS) else None
+        lib_id = rt.lib.build_id()
+        out["build"] = {"library": os.path.relpath(rt.lib.path, ROOT), "id": lib_id, "tree_id": tree,
+                        "matches_tree": (lib_id == tree) if (tree and not args.lib and not args.emulate) else None}
+    except Exception as e:                                   # (never let bookkeeping take the measurement down)
+        out["build"] = {"error": str(e)[:120]}
     if "cold_grid_ms" in head:
         # one step with a scale grid the plan has not seen (host classification + table upload + filter tables + step);
         # ms_per_step is the steady state with the row table cached

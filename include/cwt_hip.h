@@ -47,6 +47,11 @@ typedef struct cwt_plan cwt_plan;
 
 /* Library identity: "hip-gfx950" for the product build. */
 const char* cwt_backend(void);
+/* Identity of the SOURCES this binary was built from: the first 16 hex digits of a SHA-256 over pycwt_amd/csrc/* (the
+ * translation units and headers), include/cwt_hip.h and the extra compiler flags of the build (pycwt_amd/_build.py,
+ * `source_id()`).  The Python binding compares it with the tree it runs in and rebuilds -- or refuses -- on a mismatch
+ * (PYCWT_AMD_ALLOW_STALE=1 overrides); bench.py prints it.  "unknown" for a build that did not go through _build.py. */
+const char* cwt_build_id(void);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* cwt_last_error(void);
 /* Number of visible GPUs. */

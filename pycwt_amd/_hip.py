@@ -23,6 +23,7 @@ MORLET, PAUL, DOG = 0, 1, 2
 _P = C.c_void_p
 SYMBOLS = [
     ("cwt_backend", C.c_char_p, []),
+    ("cwt_build_id", C.c_char_p, []),
     ("cwt_last_error", C.c_char_p, []),
     ("cwt_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("cwt_plan_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_int64, C.c_int, C.c_int]),
@@ -111,6 +112,10 @@ class Library:
 
     def backend(self) -> str:
         return self.cwt_backend().decode()
+
+    def build_id(self) -> str:
+        """Identity of the sources this binary was built from (`_build.source_id()` of its tree at build time)."""
+        return self.cwt_build_id().decode()
 
     def check(self, rc: int):
         if rc != 0:
@@ -207,8 +212,28 @@ def load() -> Library:
     global _default
     if _default is None:
         _one_hip_runtime()
+        _check_provenance()
         _default = Library(DEFAULT_LIBRARY)
     return _default
+
+
+def _check_provenance():
+    """A library built from other sources than this tree's would be used -- and benchmarked -- silently: compare the build id
+    embedded in the file with the tree's and rebuild on a mismatch (refuse where there is no compiler;
+    PYCWT_AMD_ALLOW_STALE=1 uses the file as it is).  Installed copies without the sources are taken as they are."""
+    from . import _build
+    if not os.path.exists(DEFAULT_LIBRARY) or os.environ.get("PYCWT_AMD_ALLOW_STALE"):
+        return
+    if not all(os.path.exists(d) for d in _build.DEPS):
+        return
+    have, want = _build.library_id(DEFAULT_LIBRARY), _build.source_id()
+    if have == want:
+        return
+    try:
+        _build.build()
+    except Exception as e:
+        raise ImportError(f"{DEFAULT_LIBRARY} was built from other sources than this tree (library {have}, tree {want}) and cannot be "
+                          f"rebuilt here ({e}).  PYCWT_AMD_ALLOW_STALE=1 loads it anyway.") from e
 
 
 def _dptr(a):

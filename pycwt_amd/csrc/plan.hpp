@@ -103,7 +103,7 @@ struct cwt_plan {
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_zc = 1;         // Paul rows not clipped at Nyquist on the band-passed signal too, their profile continued through f = 0
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
-  int serial_rows = 1;     // long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
+  int serial_rows = 2;     // (complex128; complex64 plans start at 0: measured +-0 ... +1.5 % there) long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
                            // other, the preparation on the side streams (rows_launch_serial); 2 = also the first block spectra on the
                            // caller's stream (its rows follow at a kernel boundary) and the forward FFT on side stream 0
   hipEvent_t spectrum_ready = nullptr;   // (transient) set by cwt_transform when the forward FFT ran on side stream 0

@@ -61,6 +61,8 @@ def emu_library():
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
     from pycwt_amd import _hip
+    if os.environ.get("CWT_EMU_LIBRARY"):         # the sanitizer build, in a process started with build_emu.sanitizer_env()
+        return _hip.Library(os.environ["CWT_EMU_LIBRARY"])
     return _hip.Library(build_emu.build())
 
 

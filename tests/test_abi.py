@@ -27,6 +27,34 @@ def test_product_library_builds_loads_and_exports_all_symbols():
     assert lib.cwt_last_error() is not None
 
 
+def test_library_carries_the_identity_of_its_sources(tmp_path, monkeypatch):
+    """`cwt_build_id()` = `_build.source_id()` of the tree the library was built from; a library built from other sources is
+    detected from the file alone (no dlopen), rebuilt by `_build.ensure()` / `_hip.load()`, or refused where it cannot be."""
+    path = _build.build()
+    assert _build.up_to_date() and _build.library_id(path) == _build.source_id() == _hip.Library(path).build_id()
+    assert _build.source_id(["-DX=1"]) != _build.source_id()             # a -D variant is another binary
+    # a stale copy: the same file with another id inside
+    blob = open(path, "rb").read()
+    i = blob.find(_build.ID_MARKER) + len(_build.ID_MARKER)
+    stale = tmp_path / "libcwt_hip.so"
+    stale.write_bytes(blob[:i] + b"0123456789abcdef" + blob[i + 16:])
+    assert _build.library_id(str(stale)) == "0123456789abcdef"
+    monkeypatch.setattr(_build, "OUT", str(stale))
+    monkeypatch.setattr(_hip, "DEFAULT_LIBRARY", str(stale))
+    assert not _build.up_to_date()
+
+    def no_compiler(*a, **k):
+        raise RuntimeError("hipcc not found")
+    monkeypatch.setattr(_build, "build", no_compiler)
+    with pytest.raises(ImportError, match="built from other sources"):
+        _hip._check_provenance()
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _build.ensure(0)
+    monkeypatch.setenv("PYCWT_AMD_ALLOW_STALE", "1")
+    _hip._check_provenance()                                              # the override: used as it is
+    assert _build.ensure(0) == str(stale)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(ImportError, match="no CPU fallback"):
         _hip.Library(str(tmp_path / "libcwt_hip.so"))
