@@ -148,7 +148,7 @@ class Workload:
     """One BASELINE configuration on this rank: the signal, this rank's rows (j = rank mod world) of a
     `rows_total`-row scale grid, the device buffers and the plan."""
 
-    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced", pipeline=1):
+    def __init__(self, rt, config, logn, rows_total, opts, partition="balanced", pipeline=1, signal="white", auto_target=None):
         from pycwt_amd import _hip
         torch = rt.torch
         self.rt, self.config = rt, config
@@ -172,6 +172,13 @@ class Workload:
         cplx_t = torch.complex128 if self.prec == 64 else torch.complex64
         self.csize = 16 if self.prec == 64 else 8
         self.x_host = np.random.default_rng(1234).standard_normal(self.N)
+        self.signal = signal
+        if signal == "red":
+            # AR(1) noise, lag-1 autocorrelation 0.99 (the colour of geophysical series: the reference's own NINO3 / SOI samples
+            # are red), unit variance: spectrum ~ 1 / (1 - 2 g cos w + g^2), 4e4 in power between the ends
+            from scipy.signal import lfilter
+            y = lfilter([1.0], [1.0, -0.99], self.x_host)
+            self.x_host = y / y.std()
         if self.prec == 32:
             self.x_host = self.x_host.astype(np.float32)
         x = torch.empty(self.N, dtype=real_t, device=rt.dev)
@@ -189,6 +196,12 @@ class Workload:
             st = torch.cuda.Stream(device=rt.dev)
             pl.set_stream(st.cuda_stream)
             self.lanes.append((pl, st, torch.empty_like(self.W), torch.empty_like(self.xhat)))
+        if auto_target:
+            # what pycwt_amd.cwt runs by default: the tolerance that holds `auto_target` relative to every row's peak for THIS
+            # signal's spectrum (cwt_plan_auto_tolerance: the dynamic range is measured on the device)
+            self.plan.forward_fft(self.xbuf[0].data_ptr(), self.N, self.xhat.data_ptr())
+            self.auto_tolerance = self.plan.auto_tolerance(self.xhat.data_ptr(), auto_target)
+            self.plan.set_tolerance(self.auto_tolerance)
         self.tolerance = self.plan.tolerance()
         self.sharded = rt.shard[1] > 1
 
@@ -769,6 +782,11 @@ def compact_line(out, detail_path):
     short = {}
     if "c2_roundoff" in ex:
         short["c2_roundoff_ms"] = ex["c2_roundoff"]["ms_per_step"]
+    if "c2_red" in ex:                     # coloured input at the drop-in's automatic tolerance
+        short["c2_red_ms"] = ex["c2_red"]["ms_per_step"]
+        short["c2_red_tolerance"] = ex["c2_red"]["tolerance"]
+        if ex["c2_red"].get("parity"):
+            short["c2_red_max_row_err"] = ex["c2_red"]["parity"]["max_row_err"]
     for c in ("c3_paul", "c3_dog", "paul64", "dog64"):
         if c in ex and "value" in ex[c]:
             short[c + "_gs"] = ex[c]["value"]
@@ -796,8 +814,8 @@ def compact_line(out, detail_path):
     return rnd(line)
 
 
-def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True):
-    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline)
+def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True, signal="white", auto_target=None):
+    wl = Workload(rt, config, args.logn, rows_total, opts, args.partition, args.pipeline, signal=signal, auto_target=auto_target)
     if args.prime and not args.emulate:
         # the same W + K steps first from an idle device (reported as `from_idle`), then with the clocks up (the headline)
         idle = wl.timed(args.steps, args.warmup)
@@ -845,8 +863,9 @@ def measure(rt, config, args, rows_total, opts, want_cpu, traffic_passes=True):
         wl.run_steps(1)
         rt.fence()
         out["cpu_baseline"], out["parity"] = wl.cpu_and_parity()
-        out["cpu_baseline"]["reference_as_is"] = wl.reference_as_is()
-        out["cpu_baseline"]["reference_mounted"] = out["cpu_baseline"]["reference_as_is"]["reference_mounted"]
+        if signal == "white":                 # (the coloured-input block only wants the parity)
+            out["cpu_baseline"]["reference_as_is"] = wl.reference_as_is()
+            out["cpu_baseline"]["reference_mounted"] = out["cpu_baseline"]["reference_as_is"]["reference_mounted"]
     out["dtype"] = "f64" if wl.prec == 64 else "f32"
     out["label"] = wl.label
     out["tolerance"] = wl.tolerance
@@ -976,6 +995,16 @@ def main():
                                        "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"], "tolerance": r["tolerance"],
                                        "whole_path_frac": r["roofline"].get("whole_path_frac"),
                                        "row_split": r["roofline"].get("row_split"), "from_idle": r.get("from_idle")}
+        # the same grid on COLOURED input at the automatic tolerance of the drop-in (the white-noise headline is the
+        # best-case input class): AR(1) g = 0.99, target 1e-9 relative to every row's peak, every row against the oracle
+        opts_red = dict(opts)
+        opts_red.pop("tolerance", None)
+        r = measure(rt, "c2", args, rows_total, opts_red, want_cpu=True, traffic_passes=False, signal="red", auto_target=BENCH_TOLERANCE[64])
+        out["extra"]["c2_red"] = {"workload": workload + ", AR(1) g=0.99 input, cwt_plan_auto_tolerance(1e-9)", "value": r["value"],
+                                  "unit": "GSamples*scales/s", "ms_per_step": r["ms_per_step"], "tolerance": r["tolerance"],
+                                  "whole_path_frac": r["roofline"].get("whole_path_frac"),
+                                  "row_split": r["roofline"].get("row_split"), "from_idle": r.get("from_idle"),
+                                  "parity": r.get("parity")}
         out["extra"]["c1_nino3_latency"] = config1_latency()
         out["extra"]["c4_batch"] = config4_batch(rt)
         out["extra"]["c5_xwt_wct"] = config5_callers()
