@@ -47,7 +47,7 @@ typedef struct cwt_plan cwt_plan;
 
 /* Library identity: "hip-gfx950" for the product build. */
 const char* cwt_backend(void);
-/* Identity of the SOURCES this binary was built from: the first 16 hex digits of a SHA-256 over pycwt_amd/csrc/* (the
+/* Identity of the SOURCES this binary was built from: the first 16 hex digits of a SHA-256 over the files of pycwt_amd/csrc (the
  * translation units and headers), include/cwt_hip.h and the extra compiler flags of the build (pycwt_amd/_build.py,
  * `source_id()`).  The Python binding compares it with the tree it runs in and rebuilds -- or refuses -- on a mismatch
  * (PYCWT_AMD_ALLOW_STALE=1 overrides); bench.py prints it.  "unknown" for a build that did not go through _build.py. */
@@ -126,7 +126,20 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "queue_probe"  0 = take the side streams as the runtime made them (default 1: before its first long transform on a
  *                  caller's stream the plan measures -- two one-thread kernels, ~0.3 ms once -- whether its four streams
  *                  sit on four hardware queues, and replaces side streams that share one: streams created earlier in the
- *                  process, e.g. by other plans or the framework, otherwise cost 2-6 % of the step)
+ *                  process, e.g. by other plans or the framework, otherwise cost 2-6 % of the step).  THIS ONE CALL
+ *                  SYNCHRONISES the caller's stream (cwt_transform / cwt_transform_rows / cwt_transform_batch with
+ *                  nfft >= 2^18, once per caller's stream: the last eight are remembered; never while the stream is being
+ *                  captured into a graph); at most 16 streams are ever parked
+ *   "serial_rows"  long transforms with polynomial rows: 0 = overlap-save chain, band-passed rows and polynomial rows side by
+ *                  side on the plan's streams (the schedule of rounds 4-5); 1 = every kernel that WRITES W on the caller's
+ *                  stream, one after the other, everything they need prepared on the side streams; 2 = also the first block
+ *                  spectra on the caller's stream (their rows follow at a kernel boundary) and the forward FFT on a side
+ *                  stream, on half-size tiles ("fft_aside_small"); 3 = 2 with ONE wait on the caller's stream.  Default 2 for
+ *                  precision 64 (measured -1 % at config 2, -5.7 % for fp64 Paul), 0 for precision 32 (+-0 / +1.4 %)
+ *   "coef_small"   1 = the interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 as 2 / 4
+ *                  decimated 4096-point transforms per job); default 0: measured +5 % on the step (strided plane stores)
+ *   "aols_small_b" 0 = the band-passed signal's second pass on the default tile under "serial_rows" (default 1: 4096-point
+ *                  tiles, 256-thread workgroups, which find a CU beside the overlap-save rows)
  *   "graph"        1 = repeated cwt_transform calls with the same buffers and scale grid are captured into a HIP graph
  *                  and replayed (default 0: measured +-0.5 % on the step, the chain is latency bound, not launch bound)
  *   "ct"           0 = never use the compile-time specialised kernels (generic engine only)
@@ -173,6 +186,12 @@ int cwt_plan_get_tolerance(cwt_plan* plan, double* rel_tol);
 int cwt_plan_sync(cwt_plan* plan);
 
 /* ---- device memory helpers (so a NumPy-only host needs no other runtime) */
+/* Free and total device memory in bytes (hipMemGetInfo): a host that keeps device buffers between calls bounds its pool by
+ * these, not by a constant. */
+int cwt_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
+/* Blocks until everything queued on ANY stream of the device has finished (hipDeviceSynchronize): what a host needs before it
+ * hands a kept buffer to a new owner. */
+int cwt_device_synchronize(int device);
 int cwt_malloc(int device, void** ptr_dev, size_t bytes);
 int cwt_free(int device, void* ptr_dev);
 int cwt_memcpy_h2d(cwt_plan* plan, void* dst_dev, const void* src_host, size_t bytes);

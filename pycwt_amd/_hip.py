@@ -31,6 +31,8 @@ SYMBOLS = [
     ("cwt_plan_set_stream", C.c_int, [_P, _P]),
     ("cwt_plan_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("cwt_plan_sync", C.c_int, [_P]),
+    ("cwt_device_memory", C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("cwt_device_synchronize", C.c_int, [C.c_int]),
     ("cwt_malloc", C.c_int, [C.c_int, C.POINTER(_P), C.c_size_t]),
     ("cwt_free", C.c_int, [C.c_int, _P]),
     ("cwt_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -89,7 +91,11 @@ SYMBOLS = [
 
 
 class HipError(RuntimeError):
-    """A C-ABI call returned a negative status."""
+    """A C-ABI call returned a negative status (`code`: CWT_EINVAL -1, CWT_EHIP -2, CWT_ENOMEM -3, CWT_ENODEV -4)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class Library:
@@ -119,7 +125,17 @@ class Library:
 
     def check(self, rc: int):
         if rc != 0:
-            raise HipError(f"libcwt_hip error {rc}: {self.cwt_last_error().decode()}")
+            raise HipError(f"libcwt_hip error {rc}: {self.cwt_last_error().decode()}", rc)
+
+    def device_memory(self, device: int = 0):
+        """(free, total) bytes of device memory."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self.check(self.cwt_device_memory(device, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def device_synchronize(self, device: int = 0):
+        """Everything queued on any stream of the device has finished on return."""
+        self.check(self.cwt_device_synchronize(device))
 
     def device_count(self) -> int:
         n = C.c_int(0)
@@ -247,6 +263,15 @@ def _locked(method):
     @functools.wraps(method)
     def wrapper(self, *a, **kw):
         with self.lock:
+            try:
+                return method(self, *a, **kw)
+            except HipError as e:
+                # an allocation INSIDE the library failed (scratch of a transform, the buffers of cwt_execute_host, a row table):
+                # give back what the host side keeps (wavelet.release_scratch) and try once more, as DeviceBuffer does
+                if e.code != -3 or not on_allocation_failure:
+                    raise
+            for release in list(on_allocation_failure):
+                release()
             return method(self, *a, **kw)
     return wrapper
 

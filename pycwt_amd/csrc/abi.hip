@@ -158,13 +158,20 @@ static int queues_differ(cwt_plan* p, hipStream_t a, hipStream_t b, bool* differ
 }
 
 int cwtd::ensure_distinct_queues(cwt_plan* p) {
-  if (!p->queue_probe || (p->queues_probed && p->probed_main == p->stream)) return CWT_OK;
+  if (!p->queue_probe) return CWT_OK;
+  // one probe per caller's stream (a caller that alternates between two streams does not pay 0.3 ms per call), remembered for
+  // the last few; never while the caller's stream is being captured (the probe synchronises)
+  for (hipStream_t s : p->probed_streams) if (s == p->stream) return CWT_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(p->stream, &cap) != hipSuccess) (void)hipGetLastError();
+  else if (cap != hipStreamCaptureStatusNone) return CWT_OK;
   if (!p->probe_dev && hipMalloc(reinterpret_cast<void**>(&p->probe_dev), 2 * sizeof(int)) != hipSuccess)
     return fail(CWT_ENOMEM, "device allocation failed");
   if (!p->ev_probe) HIPCHECK(hipEventCreateWithFlags(&p->ev_probe, hipEventDisableTiming));
   static const bool verbose = std::getenv("CWT_QUEUE_PROBE_VERBOSE") != nullptr;
   hipStream_t* mine[3] = {&p->side[1], &p->side[0], &p->side2};     // by the work they carry: overlap-save chain first
   hipStream_t fixed[4] = {p->stream, nullptr, nullptr, nullptr};
+  bool replaced = false;
   for (int i = 0; i < 3; ++i) {
     for (int attempt = 0;; ++attempt) {
       bool ok = true;
@@ -172,16 +179,20 @@ int cwtd::ensure_distinct_queues(cwt_plan* p) {
         const int rc = queues_differ(p, fixed[j], *mine[i], &ok);
         if (rc) return rc;
       }
-      if (ok || attempt == 8) {
+      if (ok || attempt == 8 || p->spacers.size() >= 16) {          // (a busy GPU can make a probe time out: the parked streams are capped)
         if (verbose) std::fprintf(stderr, "[cwt] side stream %d: %s after %d replacement(s)\n", i, ok ? "own hardware queue" : "still shares a queue", attempt);
         break;
       }
       p->spacers.push_back(*mine[i]);                               // idle from here on; destroyed with the plan
       HIPCHECK(create_side_stream(mine[i]));
       ++p->queue_collisions;
+      replaced = true;
     }
     fixed[i + 1] = *mine[i];
   }
+  if (replaced) p->probed_streams.clear();                          // what was measured against the old side streams is stale
+  if (p->probed_streams.size() >= 8) p->probed_streams.erase(p->probed_streams.begin());
+  p->probed_streams.push_back(p->stream);
   p->queues_probed = true;
   p->probed_main = p->stream;
   return CWT_OK;
@@ -475,6 +486,17 @@ int cwt_plan_sync(cwt_plan* p) {
   return CWT_OK;
 }
 
+int cwt_device_memory(int device, size_t* free_bytes, size_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(CWT_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(device));
+  HIPCHECK(hipMemGetInfo(free_bytes, total_bytes));
+  return CWT_OK;
+}
+int cwt_device_synchronize(int device) {
+  HIPCHECK(hipSetDevice(device));
+  HIPCHECK(hipDeviceSynchronize());
+  return CWT_OK;
+}
 int cwt_malloc(int device, void** ptr, size_t bytes) {
   if (!ptr) return fail(CWT_EINVAL, "ptr is NULL");
   HIPCHECK(hipSetDevice(device));

@@ -235,7 +235,8 @@ struct cwt_plan {
   // default) in creation order; two of the plan's four streams on ONE queue run in submission order and lose their overlap
   int queue_probe = 1;               // option "queue_probe"
   bool queues_probed = false;
-  hipStream_t probed_main = nullptr; // the caller's stream the side streams were checked against
+  hipStream_t probed_main = nullptr; // the caller's stream the side streams were checked against last
+  std::vector<hipStream_t> probed_streams;   // ... and every caller's stream checked since the side streams last changed (<= 8)
   std::vector<hipStream_t> spacers;  // streams that collided: kept (idle) until the plan goes, so that their replacements land elsewhere
   int* probe_dev = nullptr;          // flag + result of the probe kernels
   hipEvent_t ev_probe = nullptr;

@@ -277,8 +277,10 @@ def wct_significance_sharded(al1, al2, dt, dj, s0, J, significance_level=0.95, w
     every rank simulates ~mc_count/G AR(1) pairs on its GPU, the per-scale histograms (rows x 1000) are
     summed with ONE all-reduce, and every rank evaluates the same percentiles.  Returns the array of
     `pycwt.wct_significance` (no disk cache here).  `rng="device"`: the surrogates are made on the GPUs
-    (`cwt_random_normal`): rank r takes the draws r, r + G, ... of ONE Philox sequence named by `seed`, so the result does
-    not depend on the number of ranks."""
+    (`cwt_random_normal`): rank r takes a CONTIGUOUS block of draws, [first_r, first_r + count_r), of ONE Philox sequence named
+    by `seed`, so the result does not depend on the number of ranks.  `seed=None`: as `wct_significance` does, a seed is drawn
+    from NumPy's global generator -- on rank 0, and broadcast (one more small collective), so that every rank names the same
+    sequence."""
     import torch
     import torch.distributed as dist
     from . import wavelet as _w
@@ -293,10 +295,15 @@ def wct_significance_sharded(al1, al2, dt, dj, s0, J, significance_level=0.95, w
     N, sj, outside, rows_with_data, maxscale = _w._mc_setup(mother, dt, dj, s0, J)
     mine = len(range(rank, mc_count, world))
     if rng == "device":
+        if seed is None:
+            box = [int(np.random.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(np.random.randint(0, 2 ** 31 - 1))]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            seed = box[0]
         # contiguous blocks of draws per rank: [first, first + mine) of the one sequence
         first = sum(len(range(r, mc_count, world)) for r in range(rank))
         hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index,
-                                rng="device", seed=int(seed or 0), first_draw=first)
+                                rng="device", seed=int(seed), first_draw=first)
     else:
         hist = _w._mc_histogram(mine, al1, al2, dt, dj, sj, N, outside, maxscale, mother, precision, device_index)
     if world > 1:

@@ -686,22 +686,41 @@ def xwt_device(y1, y2, dt, dj=1 / 12, s0=-1, J=-1, significance_level=0.95, wave
 
 # Work matrices that a call has finished with are kept for the next call instead of going back to the driver: a Monte-Carlo
 # call works in ~60 GB (77 scales x 6 M samples), and allocating / freeing that took 0.1 ... 4.7 s per call on the MI355X
-# boxes, more than the draws of a short call.  Bounded (PYCWT_AMD_SCRATCH_POOL_GB, default 64; 0 = keep nothing), emptied by
-# `release_scratch()` and whenever an allocation fails.
-_POOL_LOCK = threading.Lock()
+# boxes, more than the draws of a short call.  Bounded by a FRACTION of the card (PYCWT_AMD_SCRATCH_POOL_FRACTION of the
+# device's total memory, default 0.25: 72 GB on an MI355X, 16 GB on a 64-GB card; PYCWT_AMD_SCRATCH_POOL_GB caps it in absolute
+# terms; 0 = keep nothing), emptied by `release_scratch()` and whenever an allocation fails -- in DeviceBuffer or inside the
+# library (a plan call that returns CWT_ENOMEM runs the same hook and is retried once, _hip._locked).
+_POOL_LOCK = threading.RLock()     # re-entrant: a cyclic GC that runs while the lock is held may finalise a DeviceCoherence -> _pool_give
 _POOL: dict = {}                  # (library, device, nbytes) -> [DeviceBuffer]
 _POOL_HELD = [0]
+_POOL_TOTALS: dict = {}           # (library, device) -> total device memory in bytes
 
 
-def _pool_limit():
+def _pool_limit(lib=None, device=0):
+    """Bytes the pool may hold on this device."""
     try:
-        return int(float(os.environ.get("PYCWT_AMD_SCRATCH_POOL_GB", "64")) * 2 ** 30)
+        frac = float(os.environ.get("PYCWT_AMD_SCRATCH_POOL_FRACTION", "0.25"))
+        cap_gb = os.environ.get("PYCWT_AMD_SCRATCH_POOL_GB")
+        cap = None if cap_gb is None else int(float(cap_gb) * 2 ** 30)
     except ValueError:
         return 0
+    total = None
+    if lib is not None:
+        key = (id(lib), device)
+        total = _POOL_TOTALS.get(key)
+        if total is None:
+            try:
+                total = _POOL_TOTALS[key] = lib.device_memory(device)[1]
+            except Exception:               # (a library without the entry point: fall back to the absolute cap alone)
+                total = None
+    limit = int(frac * total) if total else (cap if cap is not None else 0)
+    if cap is not None:
+        limit = min(limit, cap)
+    return max(0, limit)
 
 
 def release_scratch():
-    """Free the device memory kept from earlier calls (see PYCWT_AMD_SCRATCH_POOL_GB)."""
+    """Free the device memory kept from earlier calls (see PYCWT_AMD_SCRATCH_POOL_FRACTION / _GB)."""
     with _POOL_LOCK:
         bufs = [b for v in _POOL.values() for b in v]
         _POOL.clear()
@@ -725,23 +744,27 @@ def _pool_take(lib, device, nbytes):
 def _pool_give(bufs):
     if not bufs:
         return
-    keep, limit = [], _pool_limit()
-    with _POOL_LOCK:
-        for b in bufs:
-            if b.ptr and _POOL_HELD[0] + b.nbytes <= limit:
+    live = [b for b in bufs if b.ptr]
+    if not live:
+        return
+    # nothing queued on ANY stream (the caller's own kernels and the plans' side streams included) may still use the buffers
+    # when their next owner gets them: an explicit device-wide wait (round 5 leaned on the one hipFree implies)
+    try:
+        live[0].lib.device_synchronize(live[0].device)
+    except Exception:
+        for b in live:                                     # cannot vouch for the buffers: give them back to the driver
+            b.free()
+        return
+    drop = []
+    with _POOL_LOCK:                                       # accounting and insertion in ONE critical section
+        for b in live:
+            if _POOL_HELD[0] + b.nbytes <= _pool_limit(b.lib, b.device):
                 _POOL_HELD[0] += b.nbytes
-                keep.append(b)
-    kept = set(map(id, keep))
-    for b in bufs:
-        if id(b) not in kept:
-            b.free()                                   # (hipFree: waits for the device, as every free did before the pool)
-    if keep:
-        # what hipFree did implicitly: nothing queued on ANY stream (the caller's own kernels included) still uses the buffers
-        # when their next owner gets them
-        _hip.DeviceBuffer(256, keep[0].device, keep[0].lib).free()
-        with _POOL_LOCK:
-            for b in keep:
                 _POOL.setdefault((id(b.lib), b.device, b.nbytes), []).append(b)
+            else:
+                drop.append(b)
+    for b in drop:
+        b.free()
 
 
 class _Scratch:
@@ -1077,7 +1100,7 @@ def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="
     filtering by `cwt_ar1_filter` for `surrogates="ar1"`) instead of by NumPy on one host thread, which is 0.10 s of a 0.13 s
     iteration at two 2^20-point series.  Same distributions, another generator: the levels agree with the NumPy path within
     the Monte-Carlo error, not seed for seed; `seed` (default: drawn from NumPy's global generator, so `np.random.seed` still
-    pins the result) names the sequence.  Cached under `..._devrng.gz`."""
+    pins the result) names the sequence.  Cached under `..._devrng.gz` (`..._devrng_seed<k>.gz` for an explicit seed)."""
     if surrogates not in ("reference", "ar1"):
         raise ValueError("surrogates must be 'reference' or 'ar1'")
     if rng not in ("numpy", "device"):
@@ -1086,6 +1109,8 @@ def wct_significance(al1, al2, dt, dj, s0, J, significance_level=0.95, wavelet="
     mother = _check_parameter_wavelet(wavelet)
     precision = _default_precision() if precision is None else int(precision)
     tag = ("_ar1" if true_ar1 else "") + ("_devrng" if rng == "device" else "")
+    if rng == "device" and seed is not None:
+        tag += f"_seed{int(seed)}"          # an explicit seed names ANOTHER result: it must not return the first seed's cached levels
     path = _mc_cache_path(al1, al2, dt, dj, s0, J, mother, tag) if cache else None
     if cache and os.path.exists(path):
         return np.loadtxt(path, unpack=True)

@@ -113,6 +113,7 @@ static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greate
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *t = size_t(8) << 30; *f = size_t(6) << 30; return hipSuccess; }   // (a small card: 8 GiB)
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0}; return hipSuccess; }
@@ -131,6 +132,8 @@ static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return 
 // graphs: not emulated -- capture is refused, the library then keeps launching plainly
 typedef struct hipemuGraph* hipGraph_t;
 typedef struct hipemuGraphExec* hipGraphExec_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorInvalidValue; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }

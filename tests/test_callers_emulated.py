@@ -6,6 +6,7 @@ import pytest
 
 import pycwt_amd
 from conftest import load_golden
+from oracle import cwt_oracle as orc
 
 
 @pytest.fixture(scope="module")
@@ -250,7 +251,7 @@ def test_wct_significance_with_surrogates_made_on_the_device(emulated, tmp_path,
     s2 = pycwt_amd.wct_significance(*al, rng="device", **dict(kw, mc_count=6))
     np.testing.assert_array_equal(s1, s2)
     pycwt_amd.wct_significance(*al, rng="device", seed=3, **dict(kw, mc_count=4, cache=True))
-    assert len(list(tmp_path.glob("wct_sig_*_devrng.gz"))) == 1
+    assert len(list(tmp_path.glob("wct_sig_*_devrng_seed3.gz"))) == 1        # (an explicit seed is part of the cache name)
     with pytest.raises(ValueError):
         pycwt_amd.wct_significance(*al, rng="gpu", **kw)
 
@@ -312,3 +313,46 @@ def test_failed_allocation_empties_the_scratch_pool_and_retries(emulated, monkey
     state["fail"] = 2                                   # still failing after the release: the error reaches the caller
     with pytest.raises(_hip.HipError):
         _hip.DeviceBuffer(1 << 20, lib=lib)
+
+
+def test_scratch_pool_is_bounded_by_the_card_and_library_allocations_retry(emulated, monkeypatch):
+    """(i) the pool's bound is a fraction of the DEVICE's memory (cwt_device_memory), not a constant: the emulated card
+    reports 8 GiB, so the default keeps at most 2 GiB, an absolute cap lowers it, a 64-GB card would never be filled by kept
+    scratch; (ii) an allocation that fails INSIDE the library (a plan call returning CWT_ENOMEM) runs the same release hook as a
+    failing DeviceBuffer and is retried once."""
+    import pycwt_amd
+    from pycwt_amd import wavelet as w, _hip
+    lib = _hip.load()
+    free, total = lib.device_memory(0)
+    assert total == 8 << 30 and 0 < free <= total
+    monkeypatch.delenv("PYCWT_AMD_SCRATCH_POOL_GB", raising=False)
+    monkeypatch.delenv("PYCWT_AMD_SCRATCH_POOL_FRACTION", raising=False)
+    assert w._pool_limit(lib, 0) == total // 4
+    monkeypatch.setenv("PYCWT_AMD_SCRATCH_POOL_FRACTION", "0.5")
+    assert w._pool_limit(lib, 0) == total // 2
+    monkeypatch.setenv("PYCWT_AMD_SCRATCH_POOL_GB", "1")
+    assert w._pool_limit(lib, 0) == 1 << 30
+    monkeypatch.delenv("PYCWT_AMD_SCRATCH_POOL_GB")
+    monkeypatch.delenv("PYCWT_AMD_SCRATCH_POOL_FRACTION")
+    rng = np.random.default_rng(10)
+    y1, y2 = rng.standard_normal(400), rng.standard_normal(400)
+    pycwt_amd.wct(y1, y2, 1.0, dj=0.5, sig=False)
+    assert w._POOL_HELD[0] > 0
+    # a plan call whose first attempt reports CWT_ENOMEM: the pool is released, the call runs again and succeeds
+    plan = _hip.Plan(1024, 64, max_rows=4, lib=lib)
+    real, state = lib.cwt_execute_host, {"fail": 1, "calls": 0}
+
+    def flaky(*a):
+        state["calls"] += 1
+        if state["fail"]:
+            state["fail"] -= 1
+            return -3                                   # CWT_ENOMEM
+        return real(*a)
+    monkeypatch.setattr(lib, "cwt_execute_host", flaky)
+    W, _ = plan.execute_host(rng.standard_normal(1000), orc.MORLET, 6.0, 1.0, np.array([4.0, 8.0]), want_xhat=False)
+    assert state["calls"] == 2 and w._POOL_HELD[0] == 0 and not w._POOL and np.isfinite(W).all()
+    state["fail"] = 2                                   # failing again after the release: the error reaches the caller, with its code
+    with pytest.raises(_hip.HipError) as e:
+        plan.execute_host(rng.standard_normal(1000), orc.MORLET, 6.0, 1.0, np.array([4.0, 8.0]), want_xhat=False)
+    assert e.value.code == -3
+    plan.close()
