@@ -148,25 +148,39 @@ __global__ void k_bluestein_band(const cplx<T>* __restrict__ xhat, const double*
 // k_icwt: out[n] = coeff * sum_j g(W[j, n]) * w[j]; POWER = false: g = Re (TC98 eq. 11 with w = 1/sqrt(s_j),
 // wavelet.py:169-170); POWER = true: g = |.|^2 (scale-averaged power with w = 1/s_j on the selected scales,
 // TC98 eq. 24 as used in sample/simple_sample.py:87-91)
+// A pure read stream over a matrix that is read once: NON-TEMPORAL loads (the lines are not kept in L2 / the Infinity Cache) and
+// 128-thread workgroups with 8 rows in flight per thread [measured, tools/microbench/icwt_read.hip, profiles/r06_icwt_read.txt:
+// plain loads 5.4-5.6 TB/s whatever the issue pattern; non-temporal 6.1, with 128-thread workgroups 6.3 TB/s].
+template <typename T>
+__device__ __forceinline__ cplx<T> load_once(const cplx<T>* p) {
+  typedef T vec2 __attribute__((vector_size(2 * sizeof(T))));
+  const vec2 v = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+  return mk<T>(v[0], v[1]);
+}
+constexpr int ICWT_THREADS = 128, ICWT_INFLIGHT = 8;
 template <typename T, bool POWER>
-__global__ void k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int nrows,
-                       const T* __restrict__ w, T coeff, T* __restrict__ out) {
+__global__ void __launch_bounds__(ICWT_THREADS)
+k_icwt(const cplx<T>* __restrict__ W, long ldw, long ncols, int nrows,
+       const T* __restrict__ w, T coeff, T* __restrict__ out) {
   const long n = long(blockIdx.x) * blockDim.x + threadIdx.x;
   if (n >= ncols) return;
-  T acc[4] = {0, 0, 0, 0};
-  int j = 0;
-  for (; j + 4 <= nrows; j += 4) {
+  constexpr int U = ICWT_INFLIGHT;
+  T acc[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const cplx<T> v = W[long(j + u) * ldw + n];
-      acc[u] += (POWER ? (v.x * v.x + v.y * v.y) : v.x) * w[j + u];
-    }
+  for (int u = 0; u < U; ++u) acc[u] = T(0);
+  int j = 0;
+  for (; j + U <= nrows; j += U) {
+    cplx<T> v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load_once<T>(W + long(j + u) * ldw + n);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] += (POWER ? (v[u].x * v[u].x + v[u].y * v[u].y) : v[u].x) * w[j + u];
   }
   for (; j < nrows; ++j) {
-    const cplx<T> v = W[long(j) * ldw + n];
+    const cplx<T> v = load_once<T>(W + long(j) * ldw + n);
     acc[0] += (POWER ? (v.x * v.x + v.y * v.y) : v.x) * w[j];
   }
-  out[n] = coeff * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  out[n] = coeff * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
 }
 
 // Cross wavelet spectrum W12 = W1 conj(W2) (pycwt/wavelet.py:399).  `out` may be W1 (every thread reads its own
@@ -302,11 +316,20 @@ __global__ void k_time_mean(const cplx<T>* __restrict__ W, long ldw, long ncols,
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   double* part = reinterpret_cast<double*>(lds_raw);
   const cplx<T>* row = W + long(blockIdx.x) * ldw;
-  double acc = 0;
-  for (long n = threadIdx.x; n < ncols; n += blockDim.x) {
-    const cplx<T> v = row[n];
-    acc += double(v.x) * double(v.x) + double(v.y) * double(v.y);
+  double a4[4] = {0, 0, 0, 0};                              // four non-temporal loads in flight per thread (a row is read once)
+  long n = threadIdx.x;
+  for (; n + 3 * long(blockDim.x) < ncols; n += 4 * long(blockDim.x)) {
+    cplx<T> v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = load_once<T>(row + n + u * long(blockDim.x));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] += double(v[u].x) * double(v[u].x) + double(v[u].y) * double(v[u].y);
   }
+  for (; n < ncols; n += blockDim.x) {
+    const cplx<T> v = load_once<T>(row + n);
+    a4[0] += double(v.x) * double(v.x) + double(v.y) * double(v.y);
+  }
+  const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   part[threadIdx.x] = acc;
   __syncthreads();
   for (int s = blockDim.x >> 1; s > 0; s >>= 1) {

@@ -338,30 +338,55 @@ __device__ __forceinline__ void ols_band_body2(const float2* __restrict__ xb0, c
       ytile[2 * q + 1] = x * gv[i].y + y * gv[i].x;
     }
   }
-  __syncthreads();
   const int sh = logN - LOGP - logx;
   const unsigned pm = (1u << (LOGP + logx)) - 1u;
-  const float2 step = twn(((unsigned(NT) * r) & pm) << sh);
-  const float2 rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
   const int c0 = ((0 - rd.k_lo) & (K - 1)) >> (LOGK - 4);
-  const int ew = 16 - c0;
-  float2 cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
   pairf re[16], im[16];
+  if constexpr (LOGK >= 8 && CWT_OLS_ROT_TABLE) {        // as ols_band_body: rotation from an LDS table, the rest folded into stage 1
+    constexpr int TB = 1 << LOGTB;
+    float2* ttab = reinterpret_cast<float2*>(ytile + 2 * K);
+    if (int(threadIdx.x) < 16 * TB) {
+      const unsigned e = threadIdx.x >> LOGTB, rr = (g << LOGTB) + (threadIdx.x & (TB - 1));
+      ttab[threadIdx.x] = (tw_all + ((16u << (LOGTB + logx)) - 2u))[rr * e];
+    }
+    __syncthreads();
+    const float2 a0 = twn(((unsigned(rd.k_lo + (f.j >> 4)) * r) & pm) << sh);
+    const float2 sigma = twn(((unsigned(NT >> 4) * r) & pm) << sh);
+    const int ew = (16 - c0) & 15;
+    const float2 phi = (tw_all + 14)[((f.j & 15) * ew) & 15];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const pairf yx = ytile[2 * (f.j + e * NT)], yy = ytile[2 * (f.j + e * NT) + 1];
-    re[e] = yx * cur.x - yy * cur.y;
-    im[e] = yx * cur.y + yy * cur.x;
-    if (e < 15) cur = cmul<float>(cur, step);
-    if (e + 1 == ew) cur = cmul<float>(cur, rhoc);                     // uniform branch
+    for (int e = 0; e < 16; ++e) {
+      const int q = f.j + (((e + ew) & 15) << (LOGK - 4));
+      const pairf yx = ytile[2 * q], yy = ytile[2 * q + 1];
+      const float2 tt = ttab[(e << LOGTB) + f.t];
+      re[e] = yx * tt.x - yy * tt.y;
+      im[e] = yx * tt.y + yy * tt.x;
+    }
+    __syncthreads();                                     // the band tile aliases the exchange buffer
+    f.run_pre(re, im, lds, tw_all + (K - 2), cmul<float>(phi, a0), sigma);
+  } else {
+    __syncthreads();
+    const float2 step = twn(((unsigned(NT) * r) & pm) << sh);
+    const float2 rhoc = twn(((0u - (r << LOGK)) & pm) << sh);           // e^{-2 pi i K r / P}
+    const int ew = 16 - c0;
+    float2 cur = twn(((unsigned(rd.k_lo + f.j + c0 * NT) * r) & pm) << sh);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const pairf yx = ytile[2 * (f.j + e * NT)], yy = ytile[2 * (f.j + e * NT) + 1];
+      re[e] = yx * cur.x - yy * cur.y;
+      im[e] = yx * cur.y + yy * cur.x;
+      if (e < 15) cur = cmul<float>(cur, step);
+      if (e + 1 == ew) cur = cmul<float>(cur, rhoc);                     // uniform branch
+    }
+    __syncthreads();                                       // the band tile aliases the exchange buffer
+    f.run(re, im, lds, tw_all + (K - 2));
   }
-  __syncthreads();                                       // the band tile aliases the exchange buffer
-  f.run(re, im, lds, tw_all + (K - 2));
+  const unsigned lim0 = nlim0 > 0 ? unsigned(nlim0) : 0u, lim1 = nlim1 > 0 ? unsigned(nlim1) : 0u;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int nl = (((f.j + e * NT) << (LOGTB + logx)) | int(r)) - H;
-    if (nl >= 0 && nl < nlim0) store_w<float>(w0 + nl, re[e][0], im[e][0]);
-    if (nl >= 0 && nl < nlim1) store_w<float>(w1 + nl, re[e][1], im[e][1]);
+    if (unsigned(nl) < lim0) store_w<float>(w0 + nl, re[e][0], im[e][0]);
+    if (unsigned(nl) < lim1) store_w<float>(w1 + nl, re[e][1], im[e][1]);
   }
 }
 

@@ -996,9 +996,9 @@ int reduce_scales_impl(cwt_plan* p, const void* W_dev, int64_t ldw, int64_t ncol
                        const double* weights, double coeff, void* out_dev) {
   int rc = upload_reals<T>(p, weights, nrows);
   if (rc) return rc;
-  const unsigned blocks = unsigned((ncols + 255) / 256);
+  const unsigned blocks = unsigned((ncols + ICWT_THREADS - 1) / ICWT_THREADS);
   return timed_launch(p, KC_ICWT, [&] {
-    hipLaunchKernelGGL((k_icwt<T, POWER>), dim3(blocks), dim3(256), 0, p->stream,
+    hipLaunchKernelGGL((k_icwt<T, POWER>), dim3(blocks), dim3(ICWT_THREADS), 0, p->stream,
                        static_cast<const cplx<T>*>(W_dev), long(ldw), long(ncols), nrows,
                        static_cast<const T*>(p->weights_dev), T(coeff), static_cast<T*>(out_dev));
   });

@@ -69,6 +69,7 @@ static inline void sincospi(double x, double* s, double* c) {
   *c = std::cos(3.14159265358979323846 * r);
 }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __builtin_nontemporal_load(p) (*(p))
 #define __expf(x) expf(x)
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::cur->smem);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

@@ -34,6 +34,50 @@ __global__ void __launch_bounds__(256) k_red(const double2* __restrict__ W, long
   }
 }
 
+// round 6: the same walk with non-temporal loads (the matrix is read once: keep it out of L2 / the Infinity Cache),
+// and with 128- / 512- / 1024-thread workgroups
+typedef double v2d __attribute__((vector_size(16)));
+template <int U, int TH>
+__global__ void __launch_bounds__(TH) k_red_nt(const double2* __restrict__ W, long ldw, long ncols, int nrows,
+                                               const double* __restrict__ w, double* __restrict__ out) {
+  const long n = long(blockIdx.x) * TH + threadIdx.x;
+  if (n >= ncols) return;
+  double acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = 0;
+  for (int j = 0; j + U <= nrows; j += U) {
+    v2d v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(W + long(j + u) * ldw + n));
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] += v[u][0] * w[j + u];
+  }
+  double s = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) s += acc[u];
+  out[n] = s;
+}
+template <int U, int TH>
+__global__ void __launch_bounds__(TH) k_red_th(const double2* __restrict__ W, long ldw, long ncols, int nrows,
+                                               const double* __restrict__ w, double* __restrict__ out) {
+  const long n = long(blockIdx.x) * TH + threadIdx.x;
+  if (n >= ncols) return;
+  double acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = 0;
+  for (int j = 0; j + U <= nrows; j += U) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = W[long(j + u) * ldw + n];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] += v[u].x * w[j + u];
+  }
+  double s = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) s += acc[u];
+  out[n] = s;
+}
+
 // rows split over blockIdx.y (partial sums, second tiny pass not timed): more workgroups, shorter chains
 template <int U>
 __global__ void __launch_bounds__(256) k_red_split(const double2* __restrict__ W, long ldw, long ncols, int nrows, int parts,
@@ -63,7 +107,14 @@ int main() {
   const long N = 1 << 20; const int rows = 256;
   double2* W; double *w, *out;
   HK(hipMalloc(&W, size_t(rows) * N * 16)); HK(hipMalloc(&w, rows * 8)); HK(hipMalloc(&out, size_t(8) * N * 8));
-  HK(hipMemset(W, 0, size_t(rows) * N * 16)); HK(hipMemset(w, 0, rows * 8));
+  {   // random-looking data (zeros clock higher: MI355X_MICROARCH.md, DVFS give-back)
+    std::vector<double> h(size_t(1) << 22);
+    unsigned s = 99u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = double(int(s)) * 4.656612873077393e-10; }
+    for (size_t off = 0; off < size_t(rows) * N * 2; off += h.size()) HK(hipMemcpy(reinterpret_cast<double*>(W) + off, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double> hw(rows, 0.5);
+    HK(hipMemcpy(w, hw.data(), rows * 8, hipMemcpyHostToDevice));
+  }
   hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
   auto time = [&](const char* what, auto launch) {
     for (int i = 0; i < 3; ++i) launch();
@@ -81,5 +132,13 @@ int main() {
   time("rows in 2 parts, 8 rows in flight", [&] { hipLaunchKernelGGL((k_red_split<8>), dim3(N / 256, 2), dim3(256), 0, 0, W, N, N, rows, 2, w, out); });
   time("rows in 4 parts, 8 rows in flight", [&] { hipLaunchKernelGGL((k_red_split<8>), dim3(N / 256, 4), dim3(256), 0, 0, W, N, N, rows, 4, w, out); });
   time("rows in 8 parts, 4 rows in flight", [&] { hipLaunchKernelGGL((k_red_split<4>), dim3(N / 256, 8), dim3(256), 0, 0, W, N, N, rows, 8, w, out); });
+  time("non-temporal loads, 4 rows in flight", [&] { hipLaunchKernelGGL((k_red_nt<4, 256>), dim3(N / 256), dim3(256), 0, 0, W, N, N, rows, w, out); });
+  time("non-temporal loads, 8 rows in flight", [&] { hipLaunchKernelGGL((k_red_nt<8, 256>), dim3(N / 256), dim3(256), 0, 0, W, N, N, rows, w, out); });
+  time("non-temporal loads, 16 rows in flight", [&] { hipLaunchKernelGGL((k_red_nt<16, 256>), dim3(N / 256), dim3(256), 0, 0, W, N, N, rows, w, out); });
+  time("non-temporal, 8 in flight, 128-thread workgroups", [&] { hipLaunchKernelGGL((k_red_nt<8, 128>), dim3(N / 128), dim3(128), 0, 0, W, N, N, rows, w, out); });
+  time("non-temporal, 8 in flight, 512-thread workgroups", [&] { hipLaunchKernelGGL((k_red_nt<8, 512>), dim3(N / 512), dim3(512), 0, 0, W, N, N, rows, w, out); });
+  time("plain, 8 in flight, 64-thread workgroups", [&] { hipLaunchKernelGGL((k_red_th<8, 64>), dim3(N / 64), dim3(64), 0, 0, W, N, N, rows, w, out); });
+  time("plain, 8 in flight, 128-thread workgroups", [&] { hipLaunchKernelGGL((k_red_th<8, 128>), dim3(N / 128), dim3(128), 0, 0, W, N, N, rows, w, out); });
+  time("plain, 8 in flight, 1024-thread workgroups", [&] { hipLaunchKernelGGL((k_red_th<8, 1024>), dim3(N / 1024), dim3(1024), 0, 0, W, N, N, rows, w, out); });
   return 0;
 }

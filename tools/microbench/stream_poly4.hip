@@ -51,6 +51,20 @@ __global__ void __launch_bounds__(256) k_fill(double2* __restrict__ W) {
   st16<true>(W + n, a, b);
 }
 
+template <int TH, bool NT, bool ZERO>
+__global__ void __launch_bounds__(TH) k_fill2(double2* __restrict__ W) {
+  const size_t n = size_t(blockIdx.y) * (size_t(1) << 20) + size_t(blockIdx.x) * TH + threadIdx.x;
+  unsigned h = unsigned(n) * 2654435761u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  const double a = ZERO ? 0.0 : double(int(h)) * 4.656612873077393e-10, b = ZERO ? 0.0 : double(int(h * 3266489917u)) * 4.656612873077393e-10;
+  st16<NT>(W + n, a, b);
+}
+// re-writes the coefficients (same values) so that they sit in the caches as k_poly_coef leaves the product's
+__global__ void k_touch(double2* p, size_t n) {
+  size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) { double2 v = p[i]; v.x += 0.0; p[i] = v; }
+}
+
 // D = degree, I = passes, TH = threads, WIDE = two adjacent outputs per lane, RUN = chunk permutation, NT = non-temporal
 template <int D, int I, int TH, bool WIDE, int RUN, bool NT>
 __global__ void __launch_bounds__(TH) k_rows(double2* __restrict__ W, const double2* __restrict__ coef, int logK,
@@ -201,6 +215,49 @@ static void fill_tables(bool zero_tw, bool zero_coef, bool smooth_coef) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "warm") {      // the fair comparison: coefficients freshly written before every launch
+    CK(hipMalloc(&W, rows * N * 16)); CK(hipMalloc(&coef, size_t(rows) * 13 * 16384 * 16)); CK(hipMalloc(&hi, 1024 * 16)); CK(hipMalloc(&lo, 1024 * 16));
+    CK(hipMalloc(&kcs, rows * 4));
+    int k[64]; for (int i = 0; i < 64; ++i) k[i] = 1000 + 37 * i;
+    CK(hipMemcpy(kcs, k, rows * 4, hipMemcpyHostToDevice));
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    fill_tables(false, false, false);
+    auto warm = [&](int logK, int D) { const size_t n = (size_t(rows) * (D + 1)) << logK; hipLaunchKernelGGL(k_touch, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, coef, n); };
+    auto timed = [&](const char* name, int D, int logK, auto launch) {
+      float tot = 0; const int reps = 8;
+      for (int i = 0; i < reps + 2; ++i) {
+        warm(logK, D);
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 2) tot += ms;
+      }
+      report(name, D, logK, tot / reps);
+    };
+    for (int rep = 0; rep < 2; ++rep) {
+      timed("fill: hash values, nt, 256 threads", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<256, true, false>), dim3(unsigned(N / 256), rows), dim3(256), 0, 0, W); });
+      timed("fill: ZERO values, nt, 256 threads", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<256, true, true>), dim3(unsigned(N / 256), rows), dim3(256), 0, 0, W); });
+      timed("fill: hash values, plain stores", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<256, false, false>), dim3(unsigned(N / 256), rows), dim3(256), 0, 0, W); });
+      timed("fill: hash values, nt, 512 threads", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<512, true, false>), dim3(unsigned(N / 512), rows), dim3(512), 0, 0, W); });
+      timed("fill: hash values, nt, 128 threads", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<128, true, false>), dim3(unsigned(N / 128), rows), dim3(128), 0, 0, W); });
+      timed("fill: hash values, nt, 64 threads", 0, 0, [&] { hipLaunchKernelGGL((k_fill2<64, true, false>), dim3(unsigned(N / 64), rows), dim3(64), 0, 0, W); });
+      for (int logK : {8, 11, 14}) {
+        const dim3 g2(unsigned(N / 512), rows), g3(unsigned(N / 768) + 1, rows);
+        auto lds = [&](unsigned span, int D) { return ((size_t(span) >> (20 - logK)) + 2) * (D + 1) * 16; };
+        timed("warm base: 2 passes", 8, logK, [&] { hipLaunchKernelGGL((k_rows<8, 2, 256, false, 1, true>), g2, dim3(256), lds(512, 8), 0, W, coef, logK, hi, lo, kcs); });
+        timed("warm run 8", 8, logK, [&] { hipLaunchKernelGGL((k_rows<8, 2, 256, false, 8, true>), g2, dim3(256), lds(512, 8), 0, W, coef, logK, hi, lo, kcs); });
+        timed("warm plain stores", 8, logK, [&] { hipLaunchKernelGGL((k_rows<8, 2, 256, false, 1, false>), g2, dim3(256), lds(512, 8), 0, W, coef, logK, hi, lo, kcs); });
+        timed("warm wg128: 4 passes", 8, logK, [&] { hipLaunchKernelGGL((k_rows<8, 4, 128, false, 1, true>), g2, dim3(128), lds(512, 8), 0, W, coef, logK, hi, lo, kcs); });
+        timed("warm wg512: 1 pass", 8, logK, [&] { hipLaunchKernelGGL((k_rows<8, 1, 512, false, 1, true>), g2, dim3(512), lds(512, 8), 0, W, coef, logK, hi, lo, kcs); });
+        const unsigned nchunks_row = unsigned(N / 512);
+        const size_t half = ((size_t(512) >> (20 - logK)) * 9 + 18);
+        if (half <= 512) {
+          timed("warm persist 2 passes, 7 WG/CU", 8, logK, [&] { hipLaunchKernelGGL((k_persist<8, 2>), dim3(256 * 7), dim3(256), 2 * half * 16, 0, W, coef, logK, hi, lo, kcs, nchunks_row, unsigned(rows)); });
+          timed("warm persist 2 passes, 4 WG/CU", 8, logK, [&] { hipLaunchKernelGGL((k_persist<8, 2>), dim3(256 * 4), dim3(256), 2 * half * 16, 0, W, coef, logK, hi, lo, kcs, nchunks_row, unsigned(rows)); });
+        }
+      }
+    }
+    return 0;
+  }
   if (argc > 1 && std::string(argv[1]) == "data") {      // what does the DATA cost?  base kernel, K' = 2^11, degree 8
     CK(hipMalloc(&W, rows * N * 16)); CK(hipMalloc(&coef, size_t(rows) * 13 * 16384 * 16)); CK(hipMalloc(&hi, 1024 * 16)); CK(hipMalloc(&lo, 1024 * 16));
     CK(hipMalloc(&kcs, rows * 4));
