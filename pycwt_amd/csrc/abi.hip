@@ -361,6 +361,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "aols_zc") p->aols_zc = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "coef_small") p->coef_small = value != 0;
+  else if (k == "poly_carrier") p->poly_carrier = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
   else if (k == "queue_probe") { p->queue_probe = value != 0; }
   else if (k == "poly_chunk_mb") { if (value < 0 || value > 4096) return fail(CWT_EINVAL, "poly_chunk_mb in [0, 4096] (0 = one chunk)"); p->poly_chunk_mb = int(value); }

@@ -689,7 +689,7 @@ k_poly_band(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
   const int K = 1 << rd.logK, q = blockIdx.x * 256 + threadIdx.x;
   if (q >= K) return;
   const int N = 1 << logN;
-  const int kc = rd.k_lo + (rd.nband >> 1), klo = rd.k_lo - kc;
+  const int kc = rd.k_lo + rd.kc_off, klo = rd.k_lo - kc;
   const int kap = klo + ((q - klo) & (K - 1));
   const cplx<T> y = filtered_bin<T>(xhat, rd, mo, kc + kap, N - 1);        // 0 outside the band
   const cplx<T> ph = twn((unsigned(kap) << (logN - rd.logK - 1)) & unsigned(N - 1));   // e^{2 pi i kappa (R/2) / N}
@@ -724,7 +724,7 @@ __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, c
       const cplx<T> v = y[e * NT];
       re[e] = v.x; im[e] = v.y;
     }
-    const int klo = -(rd.nband >> 1);                         // kappa of the first band bin
+    const int klo = -rd.kc_off;                               // kappa of the first band bin
     const T tscale = T(3.14159265358979323846 / double(K));
     const T ifact = T(inv_factorial(d));
 #pragma unroll
@@ -794,7 +794,7 @@ __device__ __forceinline__ void poly_coef_split_body(const cplx<T>* __restrict__
   if (rowi >= pc.nrows) return;                               // (uniform over the workgroup)
   const RowDesc rd = rows[pc.row_first + rowi];
   if (d > rd.nterms) return;
-  const int klo = -(rd.nband >> 1);
+  const int klo = -rd.kc_off;
   const T tscale = T(3.14159265358979323846 / double(K));
   const T ifact = T(inv_factorial(d));
   const cplx<T>* y = yb + rd.aux_off + f.j;
@@ -882,7 +882,7 @@ __device__ __forceinline__ void poly_rows_body(const RowDesc& rd, const cplx<T>*
     const unsigned i = t / unsigned(D + 1), d = t - i * unsigned(D + 1);
     sc[t] = a[(long(d) << rd.logK) + i];
   }
-  const int kc = rd.k_lo + (rd.nband >> 1);
+  const int kc = rd.k_lo + rd.kc_off;
   const unsigned nl = n0 + threadIdx.x * PT;
   cplx<T> w = twn((unsigned(kc) * nl) & nmask);
   const cplx<T> step = twn((unsigned(kc) * unsigned(SPAN)) & nmask);    // uniform: one pass further

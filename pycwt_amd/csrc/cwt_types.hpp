@@ -18,6 +18,8 @@ struct RowDesc {
   int out_row;     // destination row of W
   int logK;        // k_narrow: log2 of this row's FFT length
   int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
+  int kc_off;      // polynomial rows: carrier bin k_c = k_lo + kc_off (the band's centre for a symmetric filter; nearer the filter's
+                   // peak for a lopsided one -- Paul, DOG -- where that lowers the degree: build_row_table)
   long spec_off;   // element offset of this row's spectrum (0: all rows share one spectrum)
   long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N); rows with tables or coefficient
                    // planes of their own (overlap-save, polynomial): element offset of those

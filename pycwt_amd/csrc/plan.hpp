@@ -92,6 +92,7 @@ struct cwt_plan {
   int ols_side = 1;        // their block spectra on a side stream beside the two-pass chain
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
   int poly = 1;            // band-limited rows in polynomial form (k_poly_coef + k_poly_rows) where they fit
+  int poly_carrier = 1;    // polynomial rows: the carrier bin chosen by the filter-weighted degree bound (0 = always the band's centre)
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)

@@ -440,13 +440,14 @@ void poly_band_samples(int mother, double param, double a, int kc, int k_lo, int
     const int k = k_lo + (npts > 1 ? int((long(nband - 1) * i) / (npts - 1)) : 0);
     const double lg = profile_log_rel(mother, param, a * double(k)) - log_best;
     out->g[i] = std::isfinite(lg) ? std::exp(std::min(lg, 0.0)) : 0.0;
-    out->kap[i] = std::fabs(double(k - kc) + (k >= kc ? 1.0 : -1.0));         // + 1: the sampling skips neighbours
+    out->kap[i] = double(k - kc);                                           // signed distance from the sampling carrier kc
   }
 }
-int poly_degree_for(const PolyBandSamples& b, int logk, double eps) {
+// shift: the carrier sits `shift` bins above the one the samples were taken around
+int poly_degree_for(const PolyBandSamples& b, int logk, double eps, double shift = 0.0) {
   const double tscale = 3.14159265358979323846 / double(1 << logk);
   double term[POLY_SAMPLES], th[POLY_SAMPLES];
-  for (int i = 0; i < b.npts; ++i) { term[i] = b.g[i]; th[i] = b.kap[i] * tscale; }
+  for (int i = 0; i < b.npts; ++i) { term[i] = b.g[i]; th[i] = (std::fabs(b.kap[i] - shift) + 1.0) * tscale; }   // + 1: the sampling skips neighbours
   for (int d = 0; d <= POLY_MAX_DEGREE + 1; ++d) {
     double worst = 0;
     const double inv = 1.0 / double(d + 1);
@@ -561,6 +562,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.spec_off = rows_per_signal ? long(spec_ld) * (j / rows_per_signal) : long(spec_ld) * j;
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     rd.aux_off = 0;
+    rd.kc_off = 0;
     rd.nyq_re = rd.nyq_im = 0.0;
     double row_lo = f_lo, row_hi = f_hi, row_best = 0.0;     // row_best: log of the filter's largest value on the row's bins / its peak
     if (mother != MOTHER_TABLE) {
@@ -671,22 +673,33 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       }
       // polynomial form (k_poly_coef / k_poly_rows): K' >= the support intervals of R = N / K' >= 64 samples (128 in
       // complex64: a lane stores two outputs), degree D from the filter-weighted truncation rule
-      int poly_logk = 0, poly_deg = 0;
+      int poly_logk = 0, poly_deg = 0, poly_shift = 0;
       if (poly_ok && rd.nband > 0) {
         const int lk_max = std::min(p->poly_max_logk, p->logN - POLY_MIN_LOGR);
         const int kc = rd.k_lo + (rd.nband >> 1);
         PolyBandSamples band;
         if (std::max(8, ilog2(rd.nband)) <= lk_max) poly_band_samples(mother, param, rd.a, kc, rd.k_lo, rd.nband, row_best, &band);
+        // The carrier k_c: the band's centre minimises the largest |theta|, but the bound weighs theta by the filter -- for a
+        // lopsided filter (Paul: peak at 9 % of its band; DOG) a carrier nearer the peak needs a lower degree at the same K',
+        // i.e. fewer or shorter coefficient planes.  Candidates: centre + c nband / 16, c = -7 ... 7 (the centre wins ties).
         for (int lk = std::max(8, ilog2(rd.nband)); lk <= lk_max; ++lk) {
-          const int deg = poly_degree_for(band, lk, tol.support);
-          if (deg > POLY_MAX_DEGREE) continue;
-          poly_logk = lk; poly_deg = deg;
-          if (deg <= p->poly_degree) break;
+          int best_deg = POLY_MAX_DEGREE + 2, best_c = 0;
+          for (int c = 0; c <= (p->poly_carrier ? 7 : 0); ++c)
+            for (int sgn = (c ? -1 : 1); sgn <= 1; sgn += 2) {
+              const double shift = double(sgn * c) * double(rd.nband) / 16.0;
+              const int deg = poly_degree_for(band, lk, tol.support, std::round(shift));
+              if (deg < best_deg) { best_deg = deg; best_c = sgn * c; }
+            }
+          if (best_deg > POLY_MAX_DEGREE) continue;
+          poly_logk = lk; poly_deg = best_deg;
+          poly_shift = int(std::round(double(best_c) * double(rd.nband) / 16.0));
+          if (best_deg <= p->poly_degree) break;
         }
       }
       if (poly_logk) {
         rd.logK = poly_logk;
         rd.nterms = poly_deg;
+        rd.kc_off = (rd.nband >> 1) + poly_shift;
         poly_rows.push_back(rd);
       } else if (p->narrow && need <= narrow_cap) {
         rd.logK = need;

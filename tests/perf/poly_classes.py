@@ -1,5 +1,5 @@
 """Time of the polynomial rows per (K', degree) class: the rows of one class of a 256-scale grid transformed alone, with
-the plan's HIP-event timers (option profile).   python tests/perf/poly_classes.py [morlet|paul|dog] [precision] [tolerance]"""
+the plan's HIP-event timers (option profile).   python tests/perf/poly_classes.py [morlet|paul|dog] [precision] [tolerance] [key=value ...]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -14,7 +14,11 @@ kind, param = {"morlet": (0, 6.0), "paul": (1, 4.0), "dog": (2, 2.0)}[name]
 N = 1 << 20
 sj = bench.scale_grid(N, 1.0, bench.flambda_of(kind, param), 256)
 lib = _hip.load()
-plan = _hip.Plan(N, prec, max_rows=256, lib=lib, options={"tolerance": tol, "profile": 1})
+opts = {"tolerance": tol, "profile": 1}
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    opts[k] = int(v)
+plan = _hip.Plan(N, prec, max_rows=256, lib=lib, options=opts)
 labels = plan.classify(kind, param, 1.0, sj, N)
 groups = collections.OrderedDict()
 for j, l in enumerate(labels):
