@@ -136,6 +136,13 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  spectra on the caller's stream (their rows follow at a kernel boundary) and the forward FFT on a side
  *                  stream, on half-size tiles ("fft_aside_small"); 3 = 2 with ONE wait on the caller's stream.  Default 2 for
  *                  precision 64 (measured -1 % at config 2, -5.7 % for fp64 Paul), 0 for precision 32 (+-0 / +1.4 %)
+ *   "poly_carrier" 0 = the carrier of a polynomial row is the centre bin of its band (default 1: the bin, of 15 candidates, at which
+ *                  the filter-weighted degree bound is lowest -- for a lopsided filter (Paul, DOG) near its peak: half the
+ *                  intervals at the same degree; fp64 Paul: coefficient planes 143 -> 73 MB)
+ *   "poly_cheb"    0 = Taylor weights theta^d / d! in the interval coefficients (default 1: the weights of the Chebyshev series of
+ *                  e^{i theta u} cut at the same degree and re-expanded in monomials -- error 2 (theta/2)^(D+1) / (D+1)! instead of
+ *                  theta^(D+1) / (D+1)!, so fewer intervals at the same degree: planes -25 % at 2^20 x 256 Morlet scales; one table
+ *                  of (D + 1) x (K' + 1) reals per (K', D) pair of the scale grid, written when the grid is first seen)
  *   "coef_small"   1 = the interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 as 2 / 4
  *                  decimated 4096-point transforms per job); default 0: measured +5 % on the step (strided plane stores)
  *   "aols_small_b" 0 = the band-passed signal's second pass on the default tile under "serial_rows" (default 1: 4096-point

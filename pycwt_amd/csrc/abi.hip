@@ -35,6 +35,8 @@ int prepare_rows_table(cwt_plan* p, bool have_signal, int mother, double param, 
       rc = p->prec == 64 ? fill_ols_tables<double>(p, mother_of(mother, param)) : fill_ols_tables<float>(p, mother_of(mother, param));
     if (!rc && p->rt->n_aols)
       rc = p->prec == 64 ? fill_aols_tables<double>(p, mother_of(mother, param)) : fill_aols_tables<float>(p, mother_of(mother, param));
+    if (!rc && p->rt->poly_rtab_elems)
+      rc = p->prec == 64 ? fill_poly_tables<double>(p) : fill_poly_tables<float>(p);
     if (rc) { p->rt->key.clear(); return rc; }
   }
   set_split(p);
@@ -303,6 +305,7 @@ int cwt_plan_destroy(cwt_plan* p) {
   for (auto& t : p->slots) {
     if (t.gt_dev) (void)hipFree(t.gt_dev);
     if (t.agt_dev) (void)hipFree(t.agt_dev);
+    if (t.prt_dev) (void)hipFree(t.prt_dev);
     if (t.rows_dev) (void)hipFree(t.rows_dev);
     if (t.rows_pinned) (void)hipHostFree(t.rows_pinned);
     if (t.uploaded) (void)hipEventDestroy(t.uploaded);
@@ -362,6 +365,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "poly") p->poly = value != 0;
   else if (k == "coef_small") p->coef_small = value != 0;
   else if (k == "poly_carrier") p->poly_carrier = value != 0;
+  else if (k == "poly_cheb") p->poly_cheb = value != 0;
   else if (k == "poly_degree") { if (value < 2 || value > POLY_MAX_DEGREE) return fail(CWT_EINVAL, "poly_degree in [2, 24]"); p->poly_degree = int(value); }
   else if (k == "queue_probe") { p->queue_probe = value != 0; }
   else if (k == "poly_chunk_mb") { if (value < 0 || value > 4096) return fail(CWT_EINVAL, "poly_chunk_mb in [0, 4096] (0 = one chunk)"); p->poly_chunk_mb = int(value); }

@@ -678,6 +678,55 @@ __device__ __forceinline__ double inv_factorial(int d) {
   return t[d];
 }
 
+// Chebyshev-economised weights (option poly_cheb, the default).  e^{i theta u} = J_0(theta) + 2 sum_{k >= 1} i^k J_k(theta) T_k(u) on
+// u in [-1, 1] (Jacobi-Anger); cut at k = D the error is 2 sum_{k > D} |J_k(theta)| <= ~2 (theta/2)^(D+1) / (D+1)! -- 2^D below the
+// Taylor remainder theta^(D+1) / (D+1)! of the same degree, so the same degree serves twice the theta, i.e. HALF the intervals K'
+// (half the coefficient planes and half the short transforms behind them) for every row whose K' the degree decided.  Re-expanded
+// in monomials, T_k(u) = sum_d t_{k,d} u^d, the coefficient of u^d is i^d r_d(theta) with
+//     r_d(theta) = sum_{k = d, d + 2, ... <= D}  eps_k |t_{k,d}| J_k(theta),   |t_{k,d}| = (k/2) (k - j - 1)! / (j! d!) 2^d,  j = (k - d)/2
+// (eps_0 = 1, eps_k = 2; the signs of t_{k,d} and of i^k cancel: every term is positive for theta > 0, r_d -> theta^d / d! for small
+// theta), so k_poly_coef multiplies a band bin by r_d(theta_kappa) where it multiplied by theta^d / d!, and k_poly_rows evaluates the
+// same Horner form.  r_d depends on (K', D, d, |kappa|) only: one table of (D + 1) x (K' + 1) reals per (K', D) pair of the scale grid,
+// written once per row table; r_d(-theta) = (-1)^d r_d(theta).  grid = ((K' + 256) / 256, D + 1), evaluated in double.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_poly_rtab(int logK, int D, T* __restrict__ out) {
+  const int K = 1 << logK, q = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+  if (q > K) return;
+  const double h = 0.5 * 3.14159265358979323846 * double(q) / double(K);          // theta / 2
+  const double h2 = h * h;
+  double r = 0.0;
+  for (int k = d; k <= D; k += 2) {
+    // J_k(theta) = (theta/2)^k / k! * sum_m (-1)^m (theta/2)^(2m) / (m! (k+1)...(k+m))      (theta <= pi: 30 terms are plenty)
+    double term = 1.0, sum = 1.0;
+    for (int m = 1; m <= 30; ++m) {
+      term *= -h2 / (double(m) * double(k + m));
+      sum += term;
+    }
+    double pref = 1.0;                                       // (theta/2)^k / k!
+    for (int i = 1; i <= k; ++i) pref *= h / double(i);
+    double w = 1.0;                                          // eps_k |t_{k,d}| = k (k - j - 1)! / (j! d!) 2^d, j = (k - d) / 2  (k >= 1)
+    if (k > 0) {
+      const int j = (k - d) >> 1;
+      w = double(k);
+      if (j == 0) w /= double(d);                            // (d - 1)! / d!
+      for (int i = d + 1; i <= k - j - 1; ++i) w *= double(i);   // (k - j - 1)! / d!  (empty for j <= 1)
+      for (int i = 2; i <= j; ++i) w /= double(i);
+      for (int i = 0; i < d; ++i) w *= 2.0;
+    }
+    r += w * pref * sum;
+  }
+  out[long(d) * (K + 1) + q] = T(r);
+}
+
+// theta^d / d! (Taylor) or r_d(theta_kappa) from the row's table
+template <typename T>
+__device__ __forceinline__ T poly_weight(const T* __restrict__ rtab, const RowDesc& rd, int K, int kap, int d, T tscale, T ifact) {
+  if (rd.rtab_off < 0) return ipow<T>(T(kap) * tscale, d) * ifact;
+  const T r = rtab[rd.rtab_off + long(d) * (K + 1) + (kap < 0 ? -kap : kap)];
+  return (kap < 0 && (d & 1)) ? -r : r;
+}
+
 // The filtered, phase-shifted band of every polynomial row in the input order of its K'-point transforms:
 //   yb[band_off + q] = Y[kappa(q)] e^{i pi kappa(q) / K'},  kappa(q) = the band bin congruent to q mod K' (0 if there is none)
 // -- computed once per row (one filter evaluation per bin), read by the D + 1 transforms of the row.  grid = (K'_max / 256, rows).
@@ -704,7 +753,7 @@ k_poly_band(const cplx<T>* __restrict__ xhat, const RowDesc* __restrict__ rows, 
 template <typename T, int LOGK, int LOGP>
 __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows,
                                                const cplx<T>* __restrict__ tw_all, const PolyClass& pc,
-                                               unsigned local_wg, cplx<T>* __restrict__ coef, T* lds) {
+                                               unsigned local_wg, cplx<T>* __restrict__ coef, T* lds, const T* __restrict__ rtab) {
   constexpr int LOGTB = LOGP - LOGK, TB = 1 << LOGTB, K = 1 << LOGK, LOGNT = LOGK - 4, NT = 1 << LOGNT;
   using F = ct::Fft<T, LOGK, LOGTB, false>;
   F f;
@@ -731,7 +780,7 @@ __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, c
     for (int e = 0; e < 16; ++e) {
       const int q = f.j + e * NT;
       const int kap = klo + ((q - klo) & (K - 1));
-      const T pw = ipow<T>(T(kap) * tscale, d) * ifact;       // theta^d / d!
+      const T pw = poly_weight<T>(rtab, rd, K, kap, d, tscale, ifact);     // theta^d / d!, or its economised counterpart
       T vr = re[e] * pw, vi = im[e] * pw;
       if (d & 1) { const T tmp = vr; vr = -vi; vi = tmp; }    // times i^d
       if (d & 2) { vr = -vr; vi = -vi; }
@@ -751,7 +800,7 @@ __device__ __forceinline__ void poly_coef_body(const cplx<T>* __restrict__ yb, c
 template <typename T, int LOGP>
 __global__ void __launch_bounds__(1 << (LOGP - 4), 4)
 k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ tw_all,
-            PolyClasses cls, cplx<T>* __restrict__ coef) {
+            PolyClasses cls, cplx<T>* __restrict__ coef, const T* __restrict__ rtab) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   // the classes of this launch: log2 K' in (LOGP - 1, LOGP] for the two large tiles, <= 12 for the 4096-point tile
@@ -764,7 +813,7 @@ k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, co
   if (!found) return;
   const unsigned local = blockIdx.x - unsigned(pc.wg_first);
 #define CWT_POLY_CASE(LK) \
-  case LK: if constexpr (LK >= LK_LO && LK <= LK_HI) poly_coef_body<T, LK, LOGP>(yb, rows, tw_all, pc, local, coef, lds); break;
+  case LK: if constexpr (LK >= LK_LO && LK <= LK_HI) poly_coef_body<T, LK, LOGP>(yb, rows, tw_all, pc, local, coef, lds, rtab); break;
   switch (pc.logK) {
     CWT_POLY_CASE(8) CWT_POLY_CASE(9) CWT_POLY_CASE(10) CWT_POLY_CASE(11) CWT_POLY_CASE(12) CWT_POLY_CASE(13)
     CWT_POLY_CASE(14)
@@ -783,7 +832,7 @@ k_poly_coef(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, co
 template <typename T, int LOGS>
 __device__ __forceinline__ void poly_coef_split_body(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows,
                                                      const cplx<T>* __restrict__ tw_all, const PolyClass& pc,
-                                                     unsigned local_wg, cplx<T>* __restrict__ coef, T* lds) {
+                                                     unsigned local_wg, cplx<T>* __restrict__ coef, T* lds, const T* __restrict__ rtab) {
   constexpr int S = 1 << LOGS, LOGK = 12 + LOGS, K = 1 << LOGK, NT = 256;
   using F = ct::Fft<T, 12, 0, false>;
   F f;
@@ -813,7 +862,7 @@ __device__ __forceinline__ void poly_coef_split_body(const cplx<T>* __restrict__
       for (int e = 0; e < 8; ++e) {
         const int q = f.j + (g + e) * NT + (a << 12);
         const int kap = klo + ((q - klo) & (K - 1));
-        const T pw = ipow<T>(T(kap) * tscale, d) * ifact;     // theta^d / d!
+        const T pw = poly_weight<T>(rtab, rd, K, kap, d, tscale, ifact);     // theta^d / d!, or its economised counterpart
         T vr = v[e].x * pw, vi = v[e].y * pw;
         if (turn & 1u) { const T tmp = vr; vr = -vi; vi = tmp; }
         if (turn & 2u) { vr = -vr; vi = -vi; }
@@ -847,7 +896,7 @@ __device__ __forceinline__ void poly_coef_split_body(const cplx<T>* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(256, 4)
 k_poly_coef_all(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ tw_all,
-                PolyClasses cls, cplx<T>* __restrict__ coef) {
+                PolyClasses cls, cplx<T>* __restrict__ coef, const T* __restrict__ rtab) {
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   PolyClass pc = cls.c[0];
@@ -855,11 +904,11 @@ k_poly_coef_all(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows
   for (int i = 1; i < POLY_MAX_CLASSES; ++i)
     if (i < cls.n && int(blockIdx.x) >= cls.c[i].wg_first1) pc = cls.c[i];
   const unsigned local = blockIdx.x - unsigned(pc.wg_first1);
-#define CWT_POLY_CASE(LK) case LK: poly_coef_body<T, LK, 12>(yb, rows, tw_all, pc, local, coef, lds); break;
+#define CWT_POLY_CASE(LK) case LK: poly_coef_body<T, LK, 12>(yb, rows, tw_all, pc, local, coef, lds, rtab); break;
   switch (pc.logK) {
     CWT_POLY_CASE(8) CWT_POLY_CASE(9) CWT_POLY_CASE(10) CWT_POLY_CASE(11) CWT_POLY_CASE(12)
-    case 13: poly_coef_split_body<T, 1>(yb, rows, tw_all, pc, local, coef, lds); break;
-    case 14: poly_coef_split_body<T, 2>(yb, rows, tw_all, pc, local, coef, lds); break;
+    case 13: poly_coef_split_body<T, 1>(yb, rows, tw_all, pc, local, coef, lds, rtab); break;
+    case 14: poly_coef_split_body<T, 2>(yb, rows, tw_all, pc, local, coef, lds, rtab); break;
     default: break;
   }
 #undef CWT_POLY_CASE

@@ -20,6 +20,8 @@ struct RowDesc {
   int nterms;      // k_narrow_ct: ceil(nband / K) aliased bins per FFT input (1 unless K = 1024)
   int kc_off;      // polynomial rows: carrier bin k_c = k_lo + kc_off (the band's centre for a symmetric filter; nearer the filter's
                    // peak for a lopsided one -- Paul, DOG -- where that lowers the degree: build_row_table)
+  long rtab_off;   // polynomial rows: element offset of the row's (K', D) table of monomial weights r_d(theta_kappa) of the Chebyshev-
+                   // economised expansion (k_poly_rtab); -1 = Taylor weights theta^d / d!
   long spec_off;   // element offset of this row's spectrum (0: all rows share one spectrum)
   long tab_off;    // MOTHER_TABLE: element offset of this row's explicit filter F_j[0..N); rows with tables or coefficient
                    // planes of their own (overlap-save, polynomial): element offset of those

@@ -523,10 +523,11 @@ int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, int chu
   }, st);
   if (rc) return rc;
   const cplx<T>* tw = static_cast<const cplx<T>*>(p->tw_all);
+  const T* rtab = static_cast<const T*>(rt->prt_dev);       // economised weights of the (K', D) pairs (rows with rtab_off >= 0)
   if (p->coef_small)         // every class on 256-thread workgroups, one launch (k_poly_coef_all)
     return timed_launch(p, KC_POLY_COEF, [&] {
       hipLaunchKernelGGL((k_poly_coef_all<T>), dim3(unsigned(ch.wgs_all)), dim3(256), ((size_t(1) << 12) + (size_t(1) << 8)) * sizeof(T), st,
-                         static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, st);
+                         static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef, rtab); }, st);
   // largest tiles first: the 16384-point workgroups take a whole CU each and should find the chip as empty as it gets
   auto lds_of = [](int lp) { return ((size_t(1) << lp) + (size_t(1) << (lp - 4))) * sizeof(T); };
   const bool split = st2 && ch.wgs[2] && (ch.wgs[1] || ch.wgs[0]);
@@ -537,13 +538,13 @@ int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, int chu
   }
   if (!rc && ch.wgs[2]) rc = timed_launch(p, KC_POLY_COEF, [&] {
     hipLaunchKernelGGL((k_poly_coef<T, 14>), dim3(unsigned(ch.wgs[2])), dim3(1024), lds_of(14), st,
-                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, st);
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef, rtab); }, st);
   if (!rc && ch.wgs[1]) rc = timed_launch(p, KC_POLY_COEF, [&] {
     hipLaunchKernelGGL((k_poly_coef<T, 13>), dim3(unsigned(ch.wgs[1])), dim3(512), lds_of(13), s2,
-                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, s2);
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef, rtab); }, s2);
   if (!rc && ch.wgs[0]) rc = timed_launch(p, KC_POLY_COEF, [&] {
     hipLaunchKernelGGL((k_poly_coef<T, 12>), dim3(unsigned(ch.wgs[0])), dim3(256), lds_of(12), s2,
-                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef); }, s2);
+                       static_cast<const cplx<T>*>(band), rows, tw, ch.cls, coef, rtab); }, s2);
   if (!rc && split) {
     HIPCHECK(hipEventRecord(p->ev_big, st2));
     HIPCHECK(hipStreamWaitEvent(st, p->ev_big, 0));
@@ -926,6 +927,20 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   return CWT_OK;
 }
 
+// Tables of the economised monomial weights of the polynomial rows (k_poly_rtab), one per (K', D) pair, on the plan's stream.
+template <typename T>
+int fill_poly_tables(cwt_plan* p) {
+  cwt_plan::RowTable* t = p->rt;
+  int rc = grow(&t->prt_dev, &t->prt_bytes, size_t(t->poly_rtab_elems) * sizeof(T), p->stream);
+  if (rc) return rc;
+  T* out = static_cast<T*>(t->prt_dev);
+  for (const auto& e : t->poly_rtabs)
+    hipLaunchKernelGGL((k_poly_rtab<T>), dim3(((1u << e.logK) + 256u) / 256u, unsigned(e.deg + 1)), dim3(256), 0, p->stream, e.logK, e.deg,
+                       out + e.off);
+  HIPCHECK(hipGetLastError());
+  return CWT_OK;
+}
+
 template <typename T>
 int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, int64_t ldw, int64_t ncols) {
   int rc = grow(&p->xs, &p->xs_bytes, size_t(p->rt->ols_xs_elems) * sizeof(cplx<T>), p->stream);
@@ -1153,6 +1168,7 @@ int ar1_filter_impl(cwt_plan* p, const void* e, int64_t tau, int64_t n, double g
   X int rows_impl<T>(cwt_plan*, const void*, const Mother&, int, void*, int64_t, int64_t, const void*, int64_t);                    \
   X int fill_ols_tables<T>(cwt_plan*, const Mother&);                                                                               \
   X int fill_aols_tables<T>(cwt_plan*, const Mother&);                                                                              \
+  X int fill_poly_tables<T>(cwt_plan*);                                                                                             \
   X int launch_ols_early<T>(cwt_plan*, const void*, int64_t, void*, int64_t, int64_t);                                              \
   X int wct_products_impl<T>(cwt_plan*, const void*, const void*, const double*, int, int64_t, int64_t, void*, void*, void*);       \
   X int boxcar_impl<T>(cwt_plan*, const void*, int, int64_t, int64_t, const double*, int, void*);                                   \

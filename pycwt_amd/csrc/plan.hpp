@@ -93,6 +93,9 @@ struct cwt_plan {
   int ols_early = 1;       // cwt_transform: the whole overlap-save chain on a side stream, queued before the forward FFT
   int poly = 1;            // band-limited rows in polynomial form (k_poly_coef + k_poly_rows) where they fit
   int poly_carrier = 1;    // polynomial rows: the carrier bin chosen by the filter-weighted degree bound (0 = always the band's centre)
+  int poly_cheb = 1;       // polynomial rows: e^{i theta u} cut as its Chebyshev series (Jacobi-Anger), re-expanded in monomials -- the error of
+                           // degree D is 2 (theta/2)^(D+1) / (D+1)! instead of Taylor's theta^(D+1) / (D+1)!: 2^D smaller, i.e. half the
+                           // intervals K' at the same degree for most rows (0 = Taylor)
   int poly_degree = 8;     // preferred largest degree: the interval count K' of a row is the smallest that needs no more
   int poly_min_logn = 16;  // shortest transform that takes the form
   int poly_max_logk = 14;  // largest log2 K' (tuning: 13 keeps the rows that need 16384 intervals out of the form)
@@ -195,6 +198,12 @@ struct cwt_plan {
     };
     std::vector<PolyChunk> poly_chunks;
     long poly_coef_elems = 0, poly_band_elems = 0;
+    // tables of the economised monomial weights, one per (K', D) pair of the table: (D + 1) x (K' + 1) reals at `off` of prt_dev
+    struct PolyRtab { int logK, deg; long off; };
+    std::vector<PolyRtab> poly_rtabs;
+    long poly_rtab_elems = 0;
+    void* prt_dev = nullptr;
+    size_t prt_bytes = 0;
     int n_aols = 0, aols_first = 0, aux_first = -1, aols_logp = 12;
     int aols_nbatch = 1;                 // signals of a batched call: aols_geom.nrows rows and one mask pseudo-row (aux_first + b) each
     cwt::AolsGeom aols_geom{};

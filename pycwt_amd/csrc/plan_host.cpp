@@ -444,16 +444,23 @@ void poly_band_samples(int mother, double param, double a, int kc, int k_lo, int
   }
 }
 // shift: the carrier sits `shift` bins above the one the samples were taken around
-int poly_degree_for(const PolyBandSamples& b, int logk, double eps, double shift = 0.0) {
+// cheb: the expansion is the Chebyshev series of e^{i theta u} (Jacobi-Anger: J_0 + 2 sum_k i^k J_k(theta) T_k(u)) cut at degree D and
+// re-expanded in monomials (k_poly_rtab); what is cut is 2 sum_{k > D} |J_k(theta)| <= 2 (theta/2)^(D+1) / (D+1)! / (1 - theta / (2 D + 4))
+// -- 2^D below the Taylor remainder of the same degree.
+int poly_degree_for(const PolyBandSamples& b, int logk, double eps, double shift = 0.0, bool cheb = false) {
   const double tscale = 3.14159265358979323846 / double(1 << logk);
   double term[POLY_SAMPLES], th[POLY_SAMPLES];
-  for (int i = 0; i < b.npts; ++i) { term[i] = b.g[i]; th[i] = (std::fabs(b.kap[i] - shift) + 1.0) * tscale; }   // + 1: the sampling skips neighbours
+  for (int i = 0; i < b.npts; ++i) {
+    term[i] = cheb ? 2.0 * b.g[i] : b.g[i];
+    th[i] = (std::fabs(b.kap[i] - shift) + 1.0) * tscale * (cheb ? 0.5 : 1.0);   // + 1: the sampling skips neighbours
+  }
   for (int d = 0; d <= POLY_MAX_DEGREE + 1; ++d) {
     double worst = 0;
     const double inv = 1.0 / double(d + 1);
     for (int i = 0; i < b.npts; ++i) {
       term[i] *= th[i] * inv;
-      worst = std::max(worst, term[i]);
+      const double tail = cheb ? 1.0 / (1.0 - std::min(th[i] / double(d + 2), 0.9)) : 1.0;
+      worst = std::max(worst, term[i] * tail);
     }
     if (worst <= eps && d >= 2 && (d & 1) == 0) return d;
   }
@@ -563,6 +570,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
     rd.tab_off = (tab_ld < 0 ? long(N) : long(tab_ld)) * j;       // tab_ld = 0: every row uses the same table
     rd.aux_off = 0;
     rd.kc_off = 0;
+    rd.rtab_off = -1;
     rd.nyq_re = rd.nyq_im = 0.0;
     double row_lo = f_lo, row_hi = f_hi, row_best = 0.0;     // row_best: log of the filter's largest value on the row's bins / its peak
     if (mother != MOTHER_TABLE) {
@@ -687,7 +695,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           for (int c = 0; c <= (p->poly_carrier ? 7 : 0); ++c)
             for (int sgn = (c ? -1 : 1); sgn <= 1; sgn += 2) {
               const double shift = double(sgn * c) * double(rd.nband) / 16.0;
-              const int deg = poly_degree_for(band, lk, tol.support, std::round(shift));
+              const int deg = poly_degree_for(band, lk, tol.support, std::round(shift), p->poly_cheb != 0);
               if (deg < best_deg) { best_deg = deg; best_c = sgn * c; }
             }
           if (best_deg > POLY_MAX_DEGREE) continue;
@@ -1133,6 +1141,21 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       }
     p->rt->poly_coef_elems = off;
     p->rt->poly_band_elems = boff;
+    // tables of the economised weights: one per (K', D) pair, (D + 1) x (K' + 1) reals (|kappa| = 0 ... K'; the sign of an odd
+    // degree at negative kappa is applied by the kernel)
+    p->rt->poly_rtabs.clear();
+    p->rt->poly_rtab_elems = 0;
+    if (p->poly_cheb)
+      for (RowDesc& r : poly_rows) {
+        long at = -1;
+        for (const auto& t : p->rt->poly_rtabs) if (t.logK == r.logK && t.deg == r.nterms) at = t.off;
+        if (at < 0) {
+          at = p->rt->poly_rtab_elems;
+          p->rt->poly_rtabs.push_back({r.logK, r.nterms, at});
+          p->rt->poly_rtab_elems += (long(r.nterms) + 1) * ((1L << r.logK) + 1);
+        }
+        r.rtab_off = at;
+      }
     p->rt->table.insert(p->rt->table.end(), poly_rows.begin(), poly_rows.end());
   }
   return CWT_OK;

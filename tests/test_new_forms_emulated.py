@@ -308,3 +308,37 @@ def test_interval_coefficients_of_long_transforms_on_small_workgroups(emu_librar
     W0, _, classes0 = transform(emu_library, N, x, orc.MORLET, 6, sj, 64, {"coef_small": 0}, with_signal=False)
     assert classes0 == classes
     assert row_errors(W[big], W0[big])[0].max() < 3 * TOL[64]
+
+
+@pytest.mark.parametrize("kind,param,prec,target,bar", [
+    (orc.MORLET, 6, 64, 1e-9, 2e-10),
+    (orc.MORLET, 6, 64, 0.0, None),            # round-off: degrees up to 24
+    (orc.PAUL, 4, 64, 1e-9, 1e-9),             # lopsided filter: carrier off the band's centre, |theta| up to ~pi at the far edge
+    (orc.DOG, 2, 32, 3e-5, 1e-5),
+])
+def test_chebyshev_economised_polynomial_rows(emu_library, kind, param, prec, target, bar):
+    """Polynomial rows with the Chebyshev-economised weights (option poly_cheb, the default: k_poly_rtab) against the oracle and
+    against the Taylor weights (poly_cheb = 0) at the same accuracy target: same bar, fewer / shorter coefficient planes."""
+    N = 1 << 16
+    n0 = N - 321
+    x = np.random.default_rng(41).standard_normal(n0)
+    m = orc.Mother(kind, param)
+    sj = grid(n0, 1.0, m, 96)[24:] if kind != orc.PAUL else np.geomspace(400.0, 9000.0, 40)    # (Paul: bands of <= N / 64 bins --
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N, intended=kind == orc.PAUL)[:, :n0]                 # rows the reference drops: intended values)
+    out = {}
+    for cheb in (1, 0):
+        opts = {"poly_min_logn": 14, "poly_cheb": cheb}
+        if target:
+            opts["tolerance"] = target
+        W, split, classes = transform(emu_library, N, x, kind, param, sj, prec, opts, with_signal=False)
+        idx = [i for i, c in enumerate(classes) if c.startswith("poly/")]
+        planes = sum((int(c.split("/")[2][1:]) + 1) * int(c.split("/")[1][1:]) for c in classes if c.startswith("poly/"))
+        out[cheb] = (W, idx, planes)
+    W, idx, planes = out[1]
+    assert len(idx) >= 20 and idx == out[0][1]
+    assert planes < out[0][2], (planes, out[0][2])
+    limit = bar if bar else 3 * TOL[prec]
+    per_row, _ = row_errors(W[idx], ref[idx])
+    assert per_row.max() < limit, (per_row.argmax(), per_row.max())
+    per_row0, _ = row_errors(out[0][0][idx], ref[idx])
+    assert per_row0.max() < limit
