@@ -116,6 +116,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  gain what the extra block-spectra launch costs, EXPERIMENTS.md)
  *   "ols_small_max_halo" overlap-save rows with a halo up to this many samples (multiple of 64, default 512) run on
  *                  half-size workgroup tiles -- four block transforms in flight per CU instead of two; 0 = none
+ *   "ols_small_big" 0 = rows with a halo in ("ols_small_max_halo", 1024] on the default tile (default 1: on 8192-point blocks of TWO
+ *                  half-size tiles each where the block support is <= 512 bins -- 256-thread workgroups, four per CU, instead of one
+ *                  512-thread workgroup per block, two per CU: fp64 Morlet / DOG -0.3 ... -0.8 %, fp32 DOG -2 % of the step)
  *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)

@@ -398,17 +398,20 @@ __global__ void __launch_bounds__(1 << (LOGP - 4), (sizeof(T) == 8 ? (LOGP == 12
                                                                 : (LOGP == 12 ? CWT_LB_OLS_F32_HALF : CWT_LB_OLS_F32)))
 k_ols_ct(const cplx<T>* __restrict__ xs, const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ gtab,
          const cplx<T>* __restrict__ tw_all, TwN<T> twn, int logN, OlsClasses cls, cplx<T>* __restrict__ W, long ldw,
-         long ncols) {
+         long ncols, unsigned wg0) {
+  // wg0 (a multiple of 8): this launch covers the workgroups wg0 ... of the class list -- the classes on blocks of one tile and the
+  // classes on longer blocks go in two launches where their block spectra come from two kernels (serial schedule)
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   T* lds = reinterpret_cast<T*>(lds_raw);
   constexpr int P = 1 << LOGP;
+  const unsigned wg = blockIdx.x + wg0;
   // this workgroup's class: every class record is read from the kernel arguments at a fixed address (one round of scalar
   // loads for all 16) and selected with uniform compares -- no load whose address depends on an earlier load
   OlsClass oc = cls.c[0];
 #pragma unroll
   for (int i = 1; i < OLS_MAX_CLASSES; ++i)
-    if (int(blockIdx.x) >= cls.wg_first[i]) oc = cls.c[i];
-  const unsigned local = blockIdx.x - unsigned(oc.wg_first);
+    if (int(wg) >= cls.wg_first[i]) oc = cls.c[i];
+  const unsigned local = wg - unsigned(oc.wg_first);
   const int logx = oc.logb - LOGP;
   const unsigned g = (local >> 3) & ((1u << logx) - 1u);      // which part of the block's residues
   // (signal, block) pairs vb = signal * nblocks + block: XCD (workgroup id & 7) takes every 8th pair and walks the

@@ -348,8 +348,10 @@ int launch_ols_fwd_r(cwt_plan* p, const void* x_dev, int64_t n0, long blocks, co
                        long(p->ols_x_ld), p->rt->ols_xs_sig);
   }, st);
 }
+// (g_only / d_only >= 0: only that tile group / only its blocks of 2^d tiles; d_only = -2: every block length but one tile)
 template <typename T>
-int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, hipEvent_t after_first = nullptr, int g_only = -1) {
+int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, hipEvent_t after_first = nullptr, int g_only = -1,
+                   int d_only = -1) {
   int rc = CWT_OK;
   {
     for (int g = 0; g < 2 && !rc; ++g) {
@@ -357,7 +359,7 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, h
       const auto& G = p->rt->ols_grp[g];
       if (!G.nrows || (g_only >= 0 && g != g_only)) continue;
       for (int d = 0; d < 3 && !rc; ++d) {
-        if (!G.fwd_blocks[d]) continue;
+        if (!G.fwd_blocks[d] || (d_only >= 0 && d != d_only) || (d_only == -2 && d == 0)) continue;
         switch (G.logp + d) {                                   // log2 of the block length
           case 12: rc = launch_ols_fwd_r<T, 11>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
           case 13: rc = launch_ols_fwd_r<T, 12>(p, x_dev, n0, G.fwd_blocks[d], G.cls, st); break;
@@ -371,31 +373,34 @@ int launch_ols_fwd(cwt_plan* p, const void* x_dev, int64_t n0, hipStream_t st, h
   }
 }
 // ... and the rows themselves (k_ols_ct)
+// part: -1 = every class of the group in one launch, 0 = the classes on blocks of one tile, 1 = the classes on longer blocks
 template <typename T, int LOGP>
-int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st) {
+int launch_ols_rows_p(cwt_plan* p, int g, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int part = -1) {
   const cwt_plan::RowTable* rt = p->rt;
   const auto& G = rt->ols_grp[g];
+  const long first = part == 1 ? G.wgs_base : 0, count = part == 0 ? G.wgs_base : G.wgs - first;
+  if (count <= 0) return CWT_OK;
   static const bool once = (allow_big_lds(&k_ols_ct<T, LOGP>), true);
   (void)once;
   // (complex64: two blocks per workgroup, 8-byte exchange elements)
   const size_t lds = ((size_t(1) << LOGP) + (size_t(1) << (LOGP - 4))) * (ols_pairs(sizeof(T), LOGP) ? sizeof(pairf) : sizeof(T));
   return timed_launch(p, g == 0 ? KC_OLS_SMALL : KC_OLS, [&] {
-    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(G.wgs)), dim3(1 << (LOGP - 4)), lds, st,
+    hipLaunchKernelGGL((k_ols_ct<T, LOGP>), dim3(unsigned(count)), dim3(1 << (LOGP - 4)), lds, st,
                        static_cast<const cplx<T>*>(p->xs), rt->rows_dev + rt->ols_first + G.row_first,
                        static_cast<const cplx<T>*>(rt->gt_dev), static_cast<const cplx<T>*>(p->tw_all), twn_of<T>(p),
-                       p->logN, G.cls, W, long(ldw), long(ncols));
+                       p->logN, G.cls, W, long(ldw), long(ncols), unsigned(first));
   }, st);
 }
 template <typename T>
-int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int g_only = -1) {
+int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st, int g_only = -1, int part = -1) {
   int rc = CWT_OK;
   for (int g = 0; g < 2 && !rc; ++g) {        // the half-size tiles first (by far the longer launch since the rows with long
                                               // halos went to the polynomial form), then the default tile's rows
     const auto& G = p->rt->ols_grp[g];
     if (!G.nrows || (g_only >= 0 && g != g_only)) continue;
     switch (G.logp) {
-      case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st); break;
-      case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st); break;
+      case 12: rc = launch_ols_rows_p<T, 12>(p, g, W, ldw, ncols, st, part); break;
+      case 13: rc = launch_ols_rows_p<T, 13>(p, g, W, ldw, ncols, st, part); break;
       default: return fail(CWT_EINVAL, "overlap-save tile size");
     }
   }
@@ -630,9 +635,10 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     HIPCHECK(hipEventRecord(p->ev_a[0], S0));
   }
   if (rt->n_aols) HIPCHECK(hipStreamWaitEvent(S1, spectrum_ready, 0));   // (the rows wait for the band-passed signal, made from the spectrum)
+  const bool g0_split = p->ols_first_on_main && rt->ols_grp[0].wgs > rt->ols_grp[0].wgs_base;   // longer blocks on the half-size tiles:
   if (rt->n_ols) {                                        // block spectra queued by cwt_transform on side stream 1
     if (!p->ols_first_on_main) HIPCHECK(hipStreamWaitEvent(M, p->ev_b[0], 0));
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0);
+    rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0, g0_split ? 0 : -1);   // their spectra come from side stream 1, behind ev_ols
     if (rc) return rc;
   }
   // serial_rows = 3: ONE wait on the caller's stream for everything the side streams prepare (each wait is a barrier packet that
@@ -645,9 +651,10 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
     if (rc) return rc;
   }
-  if (rt->n_ols && rt->ols_grp[1].nrows) {
+  if (rt->n_ols && (rt->ols_grp[1].nrows || g0_split)) {
     if (!one_wait) HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
-    rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
+    if (g0_split) rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0, 1);
+    if (!rc && rt->ols_grp[1].nrows) rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
     if (rc) return rc;
   }
   if (rt->n_aols && !one_wait) {   // band-passed signal + block spectra on side stream 1 (behind the block spectra of the signal: they
@@ -948,7 +955,8 @@ int launch_ols_early(cwt_plan* p, const void* x_dev, int64_t n0, void* W_dev, in
   HIPCHECK(hipEventRecord(p->ev_fork, p->stream));        // after the previous call's work and the row-table upload
   HIPCHECK(hipStreamWaitEvent(p->side[1], p->ev_fork, 0));
   if (p->ols_first_on_main) {                           // serial_rows = 2: the first rows' spectra where the rows will follow
-    rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream, nullptr, 0);
+    rc = launch_ols_fwd<T>(p, x_dev, n0, p->stream, nullptr, 0, 0);
+    if (!rc) rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], nullptr, 0, -2);    // (the half-size tiles' longer blocks)
     if (!rc) rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], nullptr, 1);
   } else {
     rc = launch_ols_fwd<T>(p, x_dev, n0, p->side[1], p->ev_b[0]);     // (the rows follow in rows_launch)

@@ -119,6 +119,9 @@ struct cwt_plan {
   int64_t ols_x_ld = 0;    // (transient) set by cwt_transform_batch: elements between the signals of the batch
   int ols_min_logn = 18;   // shortest transform that takes the form (measured: 2^18 +12 %, 2^17 -10 %, 2^16 -13 %)
   int ols_small_max_halo = 512;   // rows with a halo up to this many samples run on half-size tiles (0 = none)
+  int ols_small_big = 1;   // half-size tiles: rows with a halo in (ols_small_max_halo, 1024] and a block support <= 1/8 tile
+                           // on blocks of TWO half-size tiles (8192 points, two 256-thread workgroups per block) instead of the default
+                           // tile (one 512-thread workgroup per 8192-point block: two per CU, the slowest row kernel of the step)
   int ols_big = 1;         // tile 8192: blocks of 2P points for rows with long halos (two workgroups per block)
   int ols_big_min_halo = 1536;   // measured: equal cost below (strided segments + twice the twiddle range against the kept fraction)
   int ols_big4_min_halo = 2048;  // ols_big = 2: rows with a halo from here on use blocks of 4P points (four workgroups per block)
@@ -174,6 +177,7 @@ struct cwt_plan {
       int logp = 13;                     // log2 of the workgroup tile
       cwt::OlsClasses cls;                    // halo classes of this group (wg_first / row_first relative to the group)
       long wgs = 0;                      // workgroups of its k_ols_ct launch
+      long wgs_base = 0;                 // ... of which the classes on blocks of ONE tile come first (their block spectra are the first to exist)
       long fwd_blocks[3] = {0, 0, 0};    // blocks of P, 2P, 4P points (k_ols_fwd_r launches)
       int row_first = 0, nrows = 0;      // its rows inside [ols_first, ols_first + n_ols)
     };

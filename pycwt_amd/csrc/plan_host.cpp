@@ -660,7 +660,16 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         };
         RowDesc big = rd;
         bool big_fits = false;
-        if (ols_logp_s && halo <= p->ols_small_max_halo) {
+        bool small_big = false;
+        if (ols_logp_s && p->ols_small_big && halo > p->ols_small_max_halo && halo <= (1 << (ols_logp_s + 1)) / 8 &&
+            p->logN >= ols_logp_s + 3) {                  // (halo <= 1/8 block: three quarters of every block transform are kept)
+          // blocks of two half-size tiles: the same 8192-point blocks as the default tile's, on 256-thread workgroups (four per CU)
+          RowDesc two = rd;
+          describe(ols_logp_s + 1, ols_logp_s, two);
+          if (two.logK <= ols_logp_s - 3) { od = two; lb = ols_logp_s + 1; grp = 0; small_big = true; }
+        }
+        if (small_big) {
+        } else if (ols_logp_s && halo <= p->ols_small_max_halo) {
           describe(ols_logp_s, ols_logp_s, od);
           lb = ols_logp_s; grp = 0;
         } else {
@@ -944,7 +953,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
   for (int g = 0; g < 2; ++g) {
     auto& G = p->rt->ols_grp[g];
     G.logp = g == 0 ? (ols_logp_s ? ols_logp_s : ols_logp) : ols_logp;
-    G.cls.n = 0; G.wgs = 0; G.fwd_blocks[0] = G.fwd_blocks[1] = G.fwd_blocks[2] = 0; G.row_first = G.nrows = 0;
+    G.cls.n = 0; G.wgs = 0; G.wgs_base = 0; G.fwd_blocks[0] = G.fwd_blocks[1] = G.fwd_blocks[2] = 0; G.row_first = G.nrows = 0;
     for (int i = 0; i < OLS_MAX_CLASSES; ++i) G.cls.wg_first[i] = 0x7fffffff;
   }
   if (!ols_rows.empty()) {
@@ -1019,6 +1028,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         }
         grp.fwd_blocks[lb - grp.logp] = blk;
         row0 += nr;
+        if (lb == grp.logp) grp.wgs_base = wg;
       }
       grp.nrows = row0 - grp.row_first;
       grp.wgs = wg;

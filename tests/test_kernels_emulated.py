@@ -324,6 +324,7 @@ def test_overlap_save_needs_the_signal_and_follows_its_options(emu_library):
     (orc.MORLET, 6, 64, {"ols_big": 0}),
     (orc.PAUL, 4, 32, {"ols_big_min_halo": 512}),
     (orc.MORLET, 6, 64, {"ols_big": 2, "ols_big4_min_halo": 1024}),   # blocks of four tiles (one 16384-point packed block spectrum)
+    (orc.MORLET, 6, 64, {"ols_small_big": 0}),             # no 8192-point blocks on pairs of half-size tiles
     (orc.MORLET, 6, 64, {"ols_small_max_halo": 0}),        # every row on the default tile
     (orc.DOG, 2, 32, {"ols_small_max_halo": 1024}),        # half-size tiles up to their limit (half the block is halo)
 ])
@@ -346,6 +347,14 @@ def test_overlap_save_block_and_tile_options(emu_library, kind, param, prec, opt
         assert bool(big) == (opts.get("ols_big", int(prec == 32)) == 1), sorted(set(classes))
     if "ols_small_max_halo" in opts:
         assert any(c.endswith("/half") for c in classes) == (opts["ols_small_max_halo"] > 0)
+    if opts == {"ols_small_big": 0}:
+        # halos in (512, 1024] with a block support <= 512 bins: on the default tile here, by default on 8192-point blocks of two
+        # half-size tiles each
+        plan = _hip.Plan(N, prec, max_rows=len(sj), lib=emu_library, options=dict(ols_min_logn=15, poly=0))
+        dflt = plan.classify(kind, param, 1.0, sj, x.size)
+        plan.close()
+        on_default_tile = lambda cl: sum(1 for c in cl if c.startswith("ols/") and not c.endswith("/half"))
+        assert on_default_tile(classes) > on_default_tile(dflt), (sorted(set(classes)), sorted(set(dflt)))
     per_row, _ = row_errors(W, orc.cwt_rows(x, 1.0, sj, m, N=N)[:, :x.size])
     assert per_row.max() < TOL[prec], (per_row.argmax(), classes[per_row.argmax()], per_row.max())
 
