@@ -146,6 +146,8 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *                  e^{i theta u} cut at the same degree and re-expanded in monomials -- error 2 (theta/2)^(D+1) / (D+1)! instead of
  *                  theta^(D+1) / (D+1)!, so fewer intervals at the same degree: planes -25 % at 2^20 x 256 Morlet scales; one table
  *                  of (D + 1) x (K' + 1) reals per (K', D) pair of the scale grid, written when the grid is first seen)
+ *   "serial_s1_once" 0 = under "serial_rows" the caller's stream waits for side stream 1 once per consumer (second overlap-save
+ *                  launch, band-passed rows); default 1: once, for the end of that in-order chain
  *   "coef_small"   1 = the interval coefficients of every K' in one launch of 256-thread workgroups (K' = 8192 / 16384 as 2 / 4
  *                  decimated 4096-point transforms per job); default 0: measured +5 % on the step (strided plane stores)
  *   "aols_small_b" 0 = the band-passed signal's second pass on the default tile under "serial_rows" (default 1: 4096-point

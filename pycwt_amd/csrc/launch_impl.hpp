@@ -411,9 +411,11 @@ int launch_ols_rows(cwt_plan* p, cplx<T>* W, int64_t ldw, int64_t ncols, hipStre
 // (the mask is the pseudo-row at aux_first: profile 1), its block spectra, then every (block, row) pair.
 // ready != nullptr (one signal only): the band-passed signal and its block spectra on st, `ready` recorded behind them,
 // the rows on st_rows behind that event.
+// phase (one signal, ready != nullptr): 0 = everything, 1 = the band-passed signal and its block spectra on st + `ready` recorded,
+// 2 = the rows on st_rows, which the CALLER has made wait for `ready`
 template <typename T, int LOGP>
 int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
-                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {      // (ready == nullptr: everything on st; the caller's stream may be the null stream)
+                  hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr, int phase = 0) {      // (ready == nullptr: everything on st; the caller's stream may be the null stream)
   const cwt_plan::RowTable* rt = p->rt;
   const AolsGeom& g = rt->aols_geom;
   constexpr int P = 1 << LOGP;
@@ -437,27 +439,28 @@ int launch_aols_p(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, in
   for (int b0 = 0; b0 < nb; b0 += chunk) {
     const int cnt = std::min(chunk, nb - b0);
     bool ok = true;
-    rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    if (phase != 2) rc = timed_launch(p, KC_AOLS_PRE, [&] {
       ok = try_pass_a_ct<T, IN_SPECTRUM>(p, logR, xhat_dev, rt->rows_dev + rt->aux_first + b0, cnt, one, 0L, 0L, Z, st);
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    if (!rc && phase != 2) rc = timed_launch(p, KC_AOLS_PRE, [&] {
       // (beside the overlap-save rows the default tile's 512-thread workgroups do not find a CU before those drain: 170-250 us
       // for 16; 256-thread workgroups get their turn)
       if (p->aols_small_b && ready && logK == 10 && default_logp<T>() == 13 && p->use_ct) { launch_pass_b_ct_lp<T, 10, 12, false>(p, nullptr, cnt, xm, p->N, p->N, Z, st); ok = true; }
       else ok = try_pass_b_ct<T, false>(p, logK, nullptr, cnt, xm, p->N, p->N, Z, st);
     }, st);
     if (!rc && !ok) rc = fail(CWT_EINVAL, "k_aols rows need the default geometry");
-    if (!rc) rc = timed_launch(p, KC_AOLS_PRE, [&] {
+    if (!rc && phase != 2) rc = timed_launch(p, KC_AOLS_PRE, [&] {
       hipLaunchKernelGGL((k_aols_fwd<T, LOGP>), dim3(unsigned(g.nblocks), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds, st, xm,
                          p->logN, g.halo, static_cast<const cplx<T>*>(p->tw_all), static_cast<cplx<T>*>(p->xsa));
     }, st);
     hipStream_t sr = st;
     if (!rc && ready && nb == 1) {
-      HIPCHECK(hipEventRecord(ready, st));
-      HIPCHECK(hipStreamWaitEvent(st_rows, ready, 0));
+      if (phase != 2) HIPCHECK(hipEventRecord(ready, st));
+      if (phase == 0) HIPCHECK(hipStreamWaitEvent(st_rows, ready, 0));
       sr = st_rows;
     }
+    if (phase == 1) return rc;
     if (!rc) rc = timed_launch(p, KC_AOLS, [&] {
       hipLaunchKernelGGL((k_aols_rows<T, LOGP>), dim3(unsigned(rt->aols_wgs), unsigned(cnt)), dim3(1 << (LOGP - 4)), lds_rows, sr,
                          static_cast<const cplx<T>*>(p->xsa), rt->rows_dev + rt->aols_first + long(b0) * g.nrows,
@@ -496,13 +499,13 @@ int launch_aols_second(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ld
 }
 template <typename T>
 int launch_aols(cwt_plan* p, const void* xhat_dev, cplx<T>* W, int64_t ldw, int64_t ncols, hipStream_t st,
-                hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr) {
+                hipStream_t st_rows = nullptr, hipEvent_t ready = nullptr, int phase = 0) {
   int rc = CWT_OK;
   switch (p->rt->aols_logp) {
-    case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, st_rows, ready); break;
+    case 12: rc = launch_aols_p<T, 12>(p, xhat_dev, W, ldw, ncols, st, st_rows, ready, phase); break;
     default: return fail(CWT_EINVAL, "k_aols tile size");
   }
-  if (!rc && p->rt->n_aols2) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, ready ? st_rows : st);
+  if (!rc && p->rt->n_aols2 && phase != 1) rc = launch_aols_second<T>(p, xhat_dev, W, ldw, ncols, ready ? st_rows : st);
   return rc;
 }
 
@@ -634,7 +637,16 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_a[0], S0));
   }
+  // side stream 1 is ONE in-order chain -- block spectra of the longer blocks / of the default tile (queued by cwt_transform), then
+  // the band-passed signal and its block spectra -- so the caller's stream waits for its END once, behind the first overlap-save
+  // launch (the chain is long done then: 130 of 250 us), instead of once per consumer: a wait costs the stream 7-8 us, a kernel
+  // boundary 2 [measured]
+  const bool s1_once = rt->n_aols && p->serial_rows != 3 && p->serial_s1_once;
   if (rt->n_aols) HIPCHECK(hipStreamWaitEvent(S1, spectrum_ready, 0));   // (the rows wait for the band-passed signal, made from the spectrum)
+  if (s1_once) {
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1], 1);
+    if (rc) return rc;
+  }
   const bool g0_split = p->ols_first_on_main && rt->ols_grp[0].wgs > rt->ols_grp[0].wgs_base;   // longer blocks on the half-size tiles:
   if (rt->n_ols) {                                        // block spectra queued by cwt_transform on side stream 1
     if (!p->ols_first_on_main) HIPCHECK(hipStreamWaitEvent(M, p->ev_b[0], 0));
@@ -651,15 +663,16 @@ int rows_launch_serial(cwt_plan* p, const void* xhat_dev, const Mother& mo, void
     rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
     if (rc) return rc;
   }
+  if (s1_once) HIPCHECK(hipStreamWaitEvent(M, p->ev_b[1], 0));
   if (rt->n_ols && (rt->ols_grp[1].nrows || g0_split)) {
-    if (!one_wait) HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
+    if (!one_wait && !s1_once) HIPCHECK(hipStreamWaitEvent(M, p->ev_ols, 0));
     if (g0_split) rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 0, 1);
     if (!rc && rt->ols_grp[1].nrows) rc = launch_ols_rows<T>(p, W, ldw, ncols, M, 1);
     if (rc) return rc;
   }
   if (rt->n_aols && !one_wait) {   // band-passed signal + block spectra on side stream 1 (behind the block spectra of the signal: they
                                    // have the two overlap-save launches to get done), the rows on the caller's stream
-    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1]);
+    rc = launch_aols<T>(p, xhat_dev, W, ldw, ncols, S1, M, p->ev_b[1], s1_once ? 2 : 0);
     if (rc) return rc;
   }
   // The polynomial rows BEFORE the two-pass rows: k_poly_rows starts every workgroup with a fetch of its coefficient sets and runs

@@ -110,6 +110,8 @@ struct cwt_plan {
   int serial_rows = 2;     // (complex128; complex64 plans start at 0: measured +-0 ... +1.5 % there) long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
                            // other, the preparation on the side streams (rows_launch_serial); 2 = also the first block spectra on the
                            // caller's stream (its rows follow at a kernel boundary) and the forward FFT on side stream 0
+  int serial_s1_once = 1;  // serial schedule: the caller's stream waits ONCE for side stream 1 (block spectra of the longer blocks, band-passed signal
+                           // and its block spectra: one in-order chain) instead of once per consumer
   hipEvent_t spectrum_ready = nullptr;   // (transient) set by cwt_transform when the forward FFT ran on side stream 0
   int fft_aside_small = 1; // serial_rows = 2: the forward FFT (on side stream 0 beside the first overlap-save rows) on half-size tiles
   int aols_small_b = 1;    // serial schedule, complex128: the band-passed signal's second pass on 4096-point tiles (256-thread workgroups)

@@ -970,7 +970,7 @@ def test_stream_placement_of_the_signal_path_keeps_every_bit(hip_library):
     sj = grid(N, 1.0, m, 256)[:128:2]                     # 64 rows: overlap-save on both tile sizes, band-passed, polynomial
     base = None
     for opts in (None, {"ols_early": 0}, {"overlap_narrow": 0}, {"overlap_narrow": 0, "ols_early": 0, "ols_side": 0},
-                 {"serial_rows": 0}, {"serial_rows": 1}, {"serial_rows": 3}):      # (the default is the serial schedule 2)
+                 {"serial_rows": 0}, {"serial_rows": 1}, {"serial_rows": 3}, {"serial_s1_once": 0}):      # (the default is the serial schedule 2)
         plan = _hip.Plan(N, 64, max_rows=64, options=dict(opts or {}, tolerance=1e-9))
         xd, xh, Wd = _hip.DeviceBuffer(x.nbytes), _hip.DeviceBuffer(N * 16), _hip.DeviceBuffer(len(sj) * N * 16)
         xd.upload(plan, x)
