@@ -922,7 +922,8 @@ k_poly_coef_all(const cplx<T>* __restrict__ yb, const RowDesc* __restrict__ rows
 template <typename T, int D>
 __device__ __forceinline__ void poly_rows_body(const RowDesc& rd, const cplx<T>* __restrict__ coef, const TwN<T>& twn,
                                                int logN, cplx<T>* __restrict__ W, long ldw, long ncols, cplx<T>* sc) {
-  constexpr int PT = sizeof(T) == 8 ? 1 : 2, SPAN = 256 * PT, I = POLY_PASSES;
+  constexpr int PT = sizeof(T) == 8 ? 1 : 2, SPAN = 256 * PT, I = POLY_PASSES, WSPAN = 64 * PT;
+  static_assert((I & (I - 1)) == 0, "POLY_PASSES: a power of two (a wavefront's span must divide the interval length)");
   const int logR = logN - rd.logK;
   const unsigned nmask = unsigned((1 << logN) - 1);
   const unsigned n0 = blockIdx.x * unsigned(SPAN * I);
@@ -934,29 +935,65 @@ __device__ __forceinline__ void poly_rows_body(const RowDesc& rd, const cplx<T>*
     const unsigned i = t / unsigned(D + 1), d = t - i * unsigned(D + 1);
     sc[t] = a[(long(d) << rd.logK) + i];
   }
+  // A wavefront covers I x WSPAN CONSECUTIVE outputs (its I passes side by side, not SPAN apart): for R >= I x WSPAN they lie in
+  // one interval, and a coefficient read from LDS serves all I x PT outputs of a lane.  The reads -- (D + 1) x 16 bytes per lane,
+  // all lanes at one address -- are what the kernel is bound by beside its stores: per class [measured, round 6 session q]
+  // D = 4 rows store 6.9 TB/s, D = 8 rows of the same K' 5.6.
   const int kc = rd.k_lo + rd.kc_off;
-  const unsigned nl = n0 + threadIdx.x * PT;
+  const unsigned nl = n0 + (threadIdx.x >> 6) * unsigned(WSPAN * I) + (threadIdx.x & 63u) * unsigned(PT);
   cplx<T> w = twn((unsigned(kc) * nl) & nmask);
-  const cplx<T> step = twn((unsigned(kc) * unsigned(SPAN)) & nmask);    // uniform: one pass further
+  const cplx<T> step = twn((unsigned(kc) * unsigned(WSPAN)) & nmask);   // uniform: one pass further
   cplx<T> adj = mk<T>(T(1), T(0));
   if constexpr (PT == 2) adj = twn(unsigned(kc) & nmask);                // e^{2 pi i k_c / N}: the lane's second output
   const T scale = T(2) / T(1u << logR);
   cplx<T>* wrow = W + long(rd.out_row) * ldw;
   __syncthreads();
+  T pr[I][PT], pi[I][PT], u[I][PT];
+#pragma unroll
+  for (int p = 0; p < I; ++p)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const unsigned ni = nl + unsigned(p * WSPAN + i);
+      u[p][i] = T(int(ni & ((1u << logR) - 1u))) * scale - T(1);
+    }
+  if ((1 << logR) >= WSPAN * I) {                                        // (uniform) one interval for the whole lane
+    const cplx<T>* c = sc + ((nl >> logR) - m0) * unsigned(D + 1);
+    const cplx<T> top = c[D];
+#pragma unroll
+    for (int p = 0; p < I; ++p)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) { pr[p][i] = top.x; pi[p][i] = top.y; }
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      const cplx<T> cd = c[d];
+#pragma unroll
+      for (int p = 0; p < I; ++p)
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { pr[p][i] = fma(pr[p][i], u[p][i], cd.x); pi[p][i] = fma(pi[p][i], u[p][i], cd.y); }
+    }
+  } else {                                                               // an interval per pass (R >= WSPAN: the PT outputs of a pass share it)
+#pragma unroll
+    for (int p = 0; p < I; ++p) {
+      const cplx<T>* c = sc + (((nl + unsigned(p * WSPAN)) >> logR) - m0) * unsigned(D + 1);
+      const cplx<T> top = c[D];
+#pragma unroll
+      for (int i = 0; i < PT; ++i) { pr[p][i] = top.x; pi[p][i] = top.y; }
+#pragma unroll
+      for (int d = D - 1; d >= 0; --d) {
+        const cplx<T> cd = c[d];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { pr[p][i] = fma(pr[p][i], u[p][i], cd.x); pi[p][i] = fma(pi[p][i], u[p][i], cd.y); }
+      }
+    }
+  }
 #pragma unroll
   for (int p = 0; p < I; ++p) {
-    const unsigned n = nl + unsigned(p * SPAN);
+    const unsigned n = nl + unsigned(p * WSPAN);
     cplx<T> o[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-      const unsigned ni = n + unsigned(i);
-      const cplx<T>* c = sc + ((ni >> logR) - m0) * unsigned(D + 1);
-      const T u = T(int(ni & ((1u << logR) - 1u))) * scale - T(1);
-      T pr = c[D].x, pi = c[D].y;
-#pragma unroll
-      for (int d = D - 1; d >= 0; --d) { const cplx<T> cd = c[d]; pr = fma(pr, u, cd.x); pi = fma(pi, u, cd.y); }
       const cplx<T> wi = i == 0 ? w : cmul<T>(w, adj);
-      o[i] = mk<T>(pr * wi.x - pi * wi.y, pr * wi.y + pi * wi.x);
+      o[i] = mk<T>(pr[p][i] * wi.x - pi[p][i] * wi.y, pr[p][i] * wi.y + pi[p][i] * wi.x);
     }
     if constexpr (PT == 1) {
       if (long(n) < ncols) store_w<T>(wrow + n, o[0].x, o[0].y);

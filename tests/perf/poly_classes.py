@@ -13,7 +13,7 @@ tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
 kind, param = {"morlet": (0, 6.0), "paul": (1, 4.0), "dog": (2, 2.0)}[name]
 N = 1 << 20
 sj = bench.scale_grid(N, 1.0, bench.flambda_of(kind, param), 256)
-lib = _hip.load()
+lib = _hip.Library(os.path.abspath(os.environ['CWT_LIB'])) if os.environ.get('CWT_LIB') else _hip.load()      # (a -D variant under tools/lab/)
 opts = {"tolerance": tol, "profile": 1}
 for kv in sys.argv[4:]:
     k, v = kv.split("=")
