@@ -777,7 +777,9 @@ int cwt_filter_rows(cwt_plan* p, const void* spec_dev, int64_t spec_ld, int moth
     int rc = mother_constant(mother, param, &cre, &cim);   // validates mother / order only
     if (!rc) rc = build_row_table(p, mother, param, a, amp_re, amp_im, spec_ld, nrows);
     if (!rc) rc = upload_row_table(p, key);
-    if (rc) return rc;
+    if (!rc && p->rt->poly_rtab_elems)                    // polynomial rows: the tables of their economised weights
+      rc = p->prec == 64 ? fill_poly_tables<double>(p) : fill_poly_tables<float>(p);
+    if (rc) { p->rt->key.clear(); return rc; }
   }
   set_split(p);
   Mother mo;

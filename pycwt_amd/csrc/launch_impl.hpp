@@ -532,6 +532,8 @@ int launch_poly_coef(cwt_plan* p, const cplx<T>* xhat, const Mother& mo, int chu
   if (rc) return rc;
   const cplx<T>* tw = static_cast<const cplx<T>*>(p->tw_all);
   const T* rtab = static_cast<const T*>(rt->prt_dev);       // economised weights of the (K', D) pairs (rows with rtab_off >= 0)
+  if (rt->poly_rtab_elems > 0 && (!rtab || rt->prt_bytes < size_t(rt->poly_rtab_elems) * sizeof(T)))
+    return fail(CWT_EINVAL, "polynomial rows without their weight tables (fill_poly_tables was not run for this row table)");
   if (p->coef_small)         // every class on 256-thread workgroups, one launch (k_poly_coef_all)
     return timed_launch(p, KC_POLY_COEF, [&] {
       hipLaunchKernelGGL((k_poly_coef_all<T>), dim3(unsigned(ch.wgs_all)), dim3(256), ((size_t(1) << 12) + (size_t(1) << 8)) * sizeof(T), st,

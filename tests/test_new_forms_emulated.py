@@ -342,3 +342,35 @@ def test_chebyshev_economised_polynomial_rows(emu_library, kind, param, prec, ta
     assert per_row.max() < limit, (per_row.argmax(), per_row.max())
     per_row0, _ = row_errors(out[0][0][idx], ref[idx])
     assert per_row0.max() < limit
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_filter_rows_takes_the_polynomial_form_with_its_weight_tables(emu_library, prec):
+    """cwt_filter_rows (the smoothing of xwt / wct: one Gaussian per row, its own spectrum per row) builds a row table of its own:
+    its polynomial rows need the tables of the economised weights like those of a transform (a table built without them made the
+    coefficient kernel read through a stale pointer: the access fault of round 6's first evidence run)."""
+    N = 1 << 16
+    n0 = N - 100
+    rows = 12
+    real, cplx = (np.float64, np.complex128) if prec == 64 else (np.float32, np.complex64)
+    es = np.dtype(real).itemsize
+    rng = np.random.default_rng(3)
+    X = (rng.standard_normal((rows, n0)) + 1j * rng.standard_normal((rows, n0))).astype(cplx)
+    s = np.geomspace(40.0, 4000.0, rows)                   # Gaussian widths in samples: exp(-0.5 (s k)^2), k = 2 pi fftfreq
+    a = s * (2 * np.pi / N)
+    plan = _hip.Plan(N, prec, max_rows=rows, lib=emu_library, options={"poly_min_logn": 14})
+    Xd, spec, out = (_hip.DeviceBuffer(X.nbytes, lib=emu_library), _hip.DeviceBuffer(2 * es * rows * N, lib=emu_library),
+                     _hip.DeviceBuffer(X.nbytes, lib=emu_library))
+    Xd.upload(plan, X)
+    plan.fft_rows(Xd.ptr, True, rows, n0, n0, spec.ptr)
+    for rep in range(2):
+        plan.filter_rows(spec.ptr, N, _hip.DOG, 0.0, a, 1.0, out.ptr, n0, n0)
+        assert plan.last_split()["poly"] >= rows // 2, plan.last_split()
+        Y = out.download(plan, (rows, n0), cplx)
+        k = 2 * np.pi * np.fft.fftfreq(N)
+        ref = np.fft.ifft(np.fft.fft(X.astype(np.complex128), N, axis=1) * np.exp(-0.5 * (s[:, None] * k[None, :]) ** 2), axis=1)[:, :n0]
+        err = np.abs(Y - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        assert err.max() < (1e-11 if prec == 64 else 2e-5), err
+    for b in (Xd, spec, out):
+        b.free()
+    plan.close()
