@@ -699,14 +699,31 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         // The carrier k_c: the band's centre minimises the largest |theta|, but the bound weighs theta by the filter -- for a
         // lopsided filter (Paul: peak at 9 % of its band; DOG) a carrier nearer the peak needs a lower degree at the same K',
         // i.e. fewer or shorter coefficient planes.  Candidates: centre + c nband / 16, c = -7 ... 7 (the centre wins ties).
+        // (a filter whose peak sits within 1/16 band of the centre -- Morlet -- keeps the centre: the search is 15 evaluations of the
+        // degree rule per K', the whole cost of classifying a new scale grid)
+        int cmax = 0;
+        if (p->poly_carrier && band.npts > 16) {
+          int ipk = 0;
+          for (int i = 1; i < band.npts; ++i) if (band.g[i] > band.g[ipk]) ipk = i;
+          if (std::abs(2 * ipk - (band.npts - 1)) * 8 > band.npts) cmax = 7;
+        }
+        bool searched = false;
+        int c_prev = 0;
         for (int lk = std::max(8, ilog2(rd.nband)); lk <= lk_max; ++lk) {
           int best_deg = POLY_MAX_DEGREE + 2, best_c = 0;
-          for (int c = 0; c <= (p->poly_carrier ? 7 : 0); ++c)
-            for (int sgn = (c ? -1 : 1); sgn <= 1; sgn += 2) {
-              const double shift = double(sgn * c) * double(rd.nband) / 16.0;
-              const int deg = poly_degree_for(band, lk, tol.support, std::round(shift), p->poly_cheb != 0);
-              if (deg < best_deg) { best_deg = deg; best_c = sgn * c; }
-            }
+          auto try_c = [&](int cc) {
+            const double shift = double(cc) * double(rd.nband) / 16.0;
+            const int deg = poly_degree_for(band, lk, tol.support, std::round(shift), p->poly_cheb != 0);
+            if (deg < best_deg || (deg == best_deg && std::abs(cc) < std::abs(best_c))) { best_deg = deg; best_c = cc; }
+          };
+          if (!searched) {                                   // all candidates at the first K', the neighbours of the winner after that
+            for (int c = 0; c <= cmax; ++c)
+              for (int sgn = (c ? -1 : 1); sgn <= 1; sgn += 2) try_c(sgn * c);
+            searched = true;
+          } else {
+            for (int cc = std::max(-cmax, c_prev - 1); cc <= std::min(cmax, c_prev + 1); ++cc) try_c(cc);
+          }
+          c_prev = best_c;
           if (best_deg > POLY_MAX_DEGREE) continue;
           poly_logk = lk; poly_deg = best_deg;
           poly_shift = int(std::round(double(best_c) * double(rd.nband) / 16.0));

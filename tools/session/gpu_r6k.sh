@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, session k: compile-time A/B on one box -- k_poly_rows asked for 8 waves per SIMD (tools/lab/libcwt_polylb8.so), wave priority
 # of the overlap-save tiles at their stores / first loads (libcwt_priost.so, libcwt_priold.so, libcwt_priost3ld.so) against the product
+# (the -D variants / diagnostics of this session were not kept: EXPERIMENTS.md R6.10-R6.12)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6k; mkdir -p $OUT
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-live-traffic"

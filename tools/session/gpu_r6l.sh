@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6, session l: serial_rows = 4 (the polynomial rows second, the preparation of the remaining row kernels beside them) against 2
+# round 6, session l: "serial_rows = 4" of that session (beside the first overlap-save launch only what the polynomial rows need,
+# k_poly_rows second, the rest of the preparation beside it) against 2 -- measured negative, not kept (EXPERIMENTS R6.10)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6l; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "stream_placement or every_row" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log

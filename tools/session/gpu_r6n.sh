@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, session n: side streams at the highest stream priority (CWT_SIDE_PRIO bit mask: 1 = side 0 (FFT, bands, 16384-point coefficient
 # tiles), 2 = side 1 (block spectra, band-passed signal), 4 = side2 (8192- / 4096-point coefficient tiles)), interleaved on one box
+# (the -D variants / diagnostics of this session were not kept: EXPERIMENTS.md R6.10-R6.12)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6n; mkdir -p $OUT
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-live-traffic"

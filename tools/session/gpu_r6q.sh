@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, session q: k_poly_rows touching the coefficient sets of the workgroup A places ahead (CWT_POLY_PREFETCH = 896 / 1792 / 3584:
 # tools/lab/libcwt_pf*.so) against the product, interleaved on one box; per (K', degree) class for 1792
+# (the -D variants / diagnostics of this session were not kept: EXPERIMENTS.md R6.10-R6.12)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6q; mkdir -p $OUT
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-live-traffic"

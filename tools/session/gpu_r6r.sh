@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, session r: k_poly_rows with a wavefront's passes side by side (one LDS read of a coefficient serves every output of a lane)
 # against the kernel before (tools/lab/libcwt_polyold.so), interleaved on one box; per (K', degree) class; parity
+# (the -D variants / diagnostics of this session were not kept: EXPERIMENTS.md R6.10-R6.12)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6r; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "every_row or round4 or chunks or golden" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, session s: passes per workgroup of the new k_poly_rows (CWT_POLY_PASSES = 1 / 4: tools/lab/libcwt_pp1.so, pp4.so) against 2
+# (the -D variants / diagnostics of this session were not kept: EXPERIMENTS.md R6.10-R6.12)
 export TMPDIR=/tmp
 OUT=gpurun_out/r6s; mkdir -p $OUT
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-live-traffic"
