@@ -77,7 +77,7 @@ bool is_pinned(const void* ptr, size_t bytes) {
 // profiles/r04_shards.txt.
 struct ShardCost { double fwd, tp_fixed, tp_row, k2048_fixed, k2048_row, ols_fixed, ols_row, olsh_fixed, olsh_row, nar_fixed, nar_row, nar_term,
                    aols_fixed, aols_row, poly_fixed, poly_row, poly_coef; };
-constexpr ShardCost kShardCost64 = {30.0, 18.0, 9.8, 30.0, 6.1, 22.0, 3.25, 44.0, 3.2, 8.0, 2.85, 0.9, 32.0, 2.9, 12.5, 2.67, 2.7};
+constexpr ShardCost kShardCost64 = {30.0, 18.0, 9.8, 30.0, 6.1, 22.0, 3.25, 44.0, 3.2, 8.0, 2.85, 0.9, 38.0, 2.9, 12.5, 2.67, 2.7};
 constexpr ShardCost kShardCost32 = {27.0, 14.0, 5.3, 8.0, 5.4, 28.0, 2.3, 20.0, 1.9, 4.0, 1.75, 0.55, 40.0, 2.3, 22.0, 1.4, 1.1};
 
 // Estimated step time of a rank that owns rows [lo, hi) (codes as cwt_plan_row_classes reports them).  nscale = transform
@@ -91,12 +91,20 @@ double shard_cost(const int* codes, int lo, int hi, const ShardCost& c, double n
     if (kind == 3) { ++n_tp; if (!seen_tp) { seen_tp = true; total += c.tp_fixed; } total += c.tp_row * nscale; }
     else if (kind == 2) { if (!seen_big) { seen_big = true; total += c.k2048_fixed; } total += c.k2048_row * nscale; }
     else if (kind == 4) { if (!seen_ols) { seen_ols = true; total += c.ols_fixed; } total += c.ols_row * nscale; }
-    else if (kind == 5) { if (!seen_olsh) { seen_olsh = true; total += c.olsh_fixed; } total += c.olsh_row * nscale; }
+    else if (kind == 5) {
+      // (round 6: the rows of the narrow block supports are the ones with the long halos -- less of every block kept, and those on
+      // 8192-point blocks come in a second launch behind their own block spectra: +10 % [measured per rank, profiles/r06_shards.txt])
+      if (!seen_olsh) { seen_olsh = true; total += c.olsh_fixed; }
+      total += c.olsh_row * nscale * (logk <= 8 ? 1.10 : 1.0);
+    }
     else if (kind == 7) {
       // stage 2 per row (a little more per degree) + the row's share of stage 1: (D + 1) K' coefficients, priced at the
       // measured 2.2 us (fp64) of a K' = 16384, D = 8 row (profiles/r04_shards.txt)
       if (!seen_poly) { seen_poly = true; total += c.poly_fixed; }
-      total += c.poly_row * nscale * (1.0 + 0.015 * std::max(0, terms - 8));
+      // (round 6, per (K', degree) class, profiles/r06_sessions.txt session r: the rows slow down with K' -- more coefficient sets per
+      // workgroup -- beyond what their share of stage 1 says: +5 % at K' = 1024, +12 % at 2048 / 4096, +10 % above)
+      const double kprime = logk >= 13 ? 0.10 : logk >= 11 ? 0.12 : logk == 10 ? 0.05 : 0.0;
+      total += c.poly_row * nscale * (1.0 + 0.015 * std::max(0, terms - 8) + kprime);
       total += c.poly_coef * double((terms + 1) << logk) / double(9 << 14);
     }
     else if (kind == 6) { if (!seen_aols) { seen_aols = true; total += c.aols_fixed * std::max(nscale, 0.5); } total += c.aols_row * nscale; }
