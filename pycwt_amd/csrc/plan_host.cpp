@@ -447,17 +447,21 @@ void poly_band_samples(int mother, double param, double a, int kc, int k_lo, int
 // cheb: the expansion is the Chebyshev series of e^{i theta u} (Jacobi-Anger: J_0 + 2 sum_k i^k J_k(theta) T_k(u)) cut at degree D and
 // re-expanded in monomials (k_poly_rtab); what is cut is 2 sum_{k > D} |J_k(theta)| <= 2 (theta/2)^(D+1) / (D+1)! / (1 - theta / (2 D + 4))
 // -- 2^D below the Taylor remainder of the same degree.
-int poly_degree_for(const PolyBandSamples& b, int logk, double eps, double shift = 0.0, bool cheb = false) {
+// dmax: degrees above it are of no interest to the caller (the search of the carrier stops a candidate where it cannot win any more)
+// stride: every stride-th sample only (the search; the degree of the winner is then taken from all samples)
+int poly_degree_for(const PolyBandSamples& b, int logk, double eps, double shift = 0.0, bool cheb = false, int dmax = POLY_MAX_DEGREE + 1,
+                    int stride = 1) {
   const double tscale = 3.14159265358979323846 / double(1 << logk);
   double term[POLY_SAMPLES], th[POLY_SAMPLES];
-  for (int i = 0; i < b.npts; ++i) {
-    term[i] = cheb ? 2.0 * b.g[i] : b.g[i];
-    th[i] = (std::fabs(b.kap[i] - shift) + 1.0) * tscale * (cheb ? 0.5 : 1.0);   // + 1: the sampling skips neighbours
+  int n = 0;
+  for (int i = 0; i < b.npts; i += stride, ++n) {
+    term[n] = cheb ? 2.0 * b.g[i] : b.g[i];
+    th[n] = (std::fabs(b.kap[i] - shift) + 1.0) * tscale * (cheb ? 0.5 : 1.0);   // + 1: the sampling skips neighbours
   }
-  for (int d = 0; d <= POLY_MAX_DEGREE + 1; ++d) {
+  for (int d = 0; d <= std::min(dmax, POLY_MAX_DEGREE + 1); ++d) {
     double worst = 0;
     const double inv = 1.0 / double(d + 1);
-    for (int i = 0; i < b.npts; ++i) {
+    for (int i = 0; i < n; ++i) {
       term[i] *= th[i] * inv;
       const double tail = cheb ? 1.0 / (1.0 - std::min(th[i] / double(d + 2), 0.9)) : 1.0;
       worst = std::max(worst, term[i] * tail);
@@ -713,7 +717,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           int best_deg = POLY_MAX_DEGREE + 2, best_c = 0;
           auto try_c = [&](int cc) {
             const double shift = double(cc) * double(rd.nband) / 16.0;
-            const int deg = poly_degree_for(band, lk, tol.support, std::round(shift), p->poly_cheb != 0);
+            const int deg = poly_degree_for(band, lk, tol.support, std::round(shift), p->poly_cheb != 0, best_deg, cmax ? 4 : 1);
             if (deg < best_deg || (deg == best_deg && std::abs(cc) < std::abs(best_c))) { best_deg = deg; best_c = cc; }
           };
           if (!searched) {                                   // all candidates at the first K', the neighbours of the winner after that
@@ -724,6 +728,8 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
             for (int cc = std::max(-cmax, c_prev - 1); cc <= std::min(cmax, c_prev + 1); ++cc) try_c(cc);
           }
           c_prev = best_c;
+          if (cmax && best_deg <= POLY_MAX_DEGREE)            // the winner's degree from every sample
+            best_deg = poly_degree_for(band, lk, tol.support, std::round(double(best_c) * double(rd.nband) / 16.0), p->poly_cheb != 0);
           if (best_deg > POLY_MAX_DEGREE) continue;
           poly_logk = lk; poly_deg = best_deg;
           poly_shift = int(std::round(double(best_c) * double(rd.nband) / 16.0));
