@@ -1011,6 +1011,108 @@ __device__ __forceinline__ void poly_rows_body(const RowDesc& rd, const cplx<T>*
   }
 }
 
+// Rows of degree <= CWT_POLY_SCALAR_D64 / _D32 (complex128 / complex64) take their coefficient sets through the scalar data path
+// (poly_rows_body_s: no LDS, no barrier, 32 vector registers), the others stage them in LDS (poly_rows_body).  [measured, round 6
+// sessions y - ab, per (K', degree) class in complex128: D = 4 rows 2.59 -> 2.39 us per row (7.0 TB/s), D = 6 2.54 -> 2.71, D = 8 2.88 ->
+// 3.31 -- nine scalar round trips per wavefront cost more than one LDS staging per workgroup; config 2 with D <= 4: -0.7 ... -0.9 %.
+// complex64: not used -- a pass of a wavefront is 128 outputs there, two intervals at R = 64 (two sets and a select per lane: 71
+// registers), and the step is +0.9 % (five interleaved repeats, Paul and DOG) although a first, all-scalar build looked better]
+#ifndef CWT_POLY_SCALAR_D64
+#define CWT_POLY_SCALAR_D64 4
+#endif
+#ifndef CWT_POLY_SCALAR_D32
+#define CWT_POLY_SCALAR_D32 0
+#endif
+__device__ __forceinline__ unsigned wave_uniform(unsigned v) {
+#if defined(__AMDGCN__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+// As poly_rows_body, but a wavefront reads the coefficient set(s) of its own interval(s) itself: the addresses are uniform over the
+// wavefront (R >= 64 outputs of one pass lie in one interval), so the loads are scalar loads and the Horner FMAs take the coefficient from
+// scalar registers -- no staging in LDS, no workgroup barrier, no LDS reads.
+template <typename T, int D>
+__device__ __forceinline__ void poly_rows_body_s(const RowDesc& rd, const cplx<T>* __restrict__ coef, const TwN<T>& twn,
+                                                 int logN, cplx<T>* __restrict__ W, long ldw, long ncols) {
+  constexpr int PT = sizeof(T) == 8 ? 1 : 2, SPAN = 256 * PT, I = POLY_PASSES, WSPAN = 64 * PT;
+  const int logR = logN - rd.logK;
+  const unsigned nmask = unsigned((1 << logN) - 1);
+  const unsigned n0 = blockIdx.x * unsigned(SPAN * I);
+  const unsigned nw = n0 + wave_uniform(threadIdx.x >> 6) * unsigned(WSPAN * I);      // first output of this wavefront
+  const unsigned nl = nw + (threadIdx.x & 63u) * unsigned(PT);
+  const int kc = rd.k_lo + rd.kc_off;
+  cplx<T> w = twn((unsigned(kc) * nl) & nmask);
+  const cplx<T> step = twn((unsigned(kc) * unsigned(WSPAN)) & nmask);
+  cplx<T> adj = mk<T>(T(1), T(0));
+  if constexpr (PT == 2) adj = twn(unsigned(kc) & nmask);
+  const T scale = T(2) / T(1u << logR);
+  cplx<T>* wrow = W + long(rd.out_row) * ldw;
+  const cplx<T>* a = coef + rd.tab_off;
+  T pr[I][PT], pi[I][PT], u[I][PT];
+#pragma unroll
+  for (int p = 0; p < I; ++p)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const unsigned ni = nl + unsigned(p * WSPAN + i);
+      u[p][i] = T(int(ni & ((1u << logR) - 1u))) * scale - T(1);
+    }
+  if ((1 << logR) >= WSPAN * I) {
+    const cplx<T>* c = a + ((nw & nmask) >> logR);
+    const cplx<T> top = c[long(D) << rd.logK];
+#pragma unroll
+    for (int p = 0; p < I; ++p)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) { pr[p][i] = top.x; pi[p][i] = top.y; }
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      const cplx<T> cd = c[long(d) << rd.logK];
+#pragma unroll
+      for (int p = 0; p < I; ++p)
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { pr[p][i] = fma(pr[p][i], u[p][i], cd.x); pi[p][i] = fma(pi[p][i], u[p][i], cd.y); }
+    }
+  } else {                                                               // an interval per pass (R >= WSPAN: see k_poly_rows)
+#pragma unroll
+    for (int p = 0; p < I; ++p) {
+      const cplx<T>* c = a + (((nw + unsigned(p * WSPAN)) & nmask) >> logR);
+      const cplx<T> top = c[long(D) << rd.logK];
+#pragma unroll
+      for (int i = 0; i < PT; ++i) { pr[p][i] = top.x; pi[p][i] = top.y; }
+#pragma unroll
+      for (int d = D - 1; d >= 0; --d) {
+        const cplx<T> cd = c[long(d) << rd.logK];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { pr[p][i] = fma(pr[p][i], u[p][i], cd.x); pi[p][i] = fma(pi[p][i], u[p][i], cd.y); }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < I; ++p) {
+    const unsigned n = nl + unsigned(p * WSPAN);
+    cplx<T> o[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const cplx<T> wi = i == 0 ? w : cmul<T>(w, adj);
+      o[i] = mk<T>(pr[p][i] * wi.x - pi[p][i] * wi.y, pr[p][i] * wi.y + pi[p][i] * wi.x);
+    }
+    if constexpr (PT == 1) {
+      if (long(n) < ncols) store_w<T>(wrow + n, o[0].x, o[0].y);
+    } else {
+      if (long(n) + 1 < ncols && ((reinterpret_cast<size_t>(wrow + n) & 15u) == 0)) {
+        typedef T vec4 __attribute__((vector_size(4 * sizeof(T))));
+        vec4 v = {o[0].x, o[0].y, o[PT - 1].x, o[PT - 1].y};
+        __builtin_nontemporal_store(v, reinterpret_cast<vec4*>(wrow + n));
+      } else {
+        if (long(n) < ncols) store_w<T>(wrow + n, o[0].x, o[0].y);
+        if (long(n) + 1 < ncols) store_w<T>(wrow + n + 1, o[PT - 1].x, o[PT - 1].y);
+      }
+    }
+    if (p + 1 < I) w = cmul<T>(w, step);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_poly_rows(const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ coef, TwN<T> twn, int logN,
@@ -1018,7 +1120,13 @@ k_poly_rows(const RowDesc* __restrict__ rows, const cplx<T>* __restrict__ coef, 
   HIP_DYNAMIC_SHARED(double2, lds_raw)
   cplx<T>* sc = reinterpret_cast<cplx<T>*>(lds_raw);
   const RowDesc rd = rows[blockIdx.y];
-#define CWT_POLYR_CASE(DD) case DD: poly_rows_body<T, DD>(rd, coef, twn, logN, W, ldw, ncols, sc); break;
+  constexpr int SMAX = sizeof(T) == 8 ? CWT_POLY_SCALAR_D64 : CWT_POLY_SCALAR_D32;
+  static_assert(sizeof(T) == 8 || SMAX == 0, "poly_rows_body_s: one interval per pass of a wavefront (R >= 128 in complex64 is not guaranteed)");
+#define CWT_POLYR_CASE(DD)                                                                      \
+  case DD:                                                                                      \
+    if constexpr (DD <= SMAX) poly_rows_body_s<T, DD>(rd, coef, twn, logN, W, ldw, ncols);      \
+    else poly_rows_body<T, DD>(rd, coef, twn, logN, W, ldw, ncols, sc);                         \
+    break;
   switch (rd.nterms) {
     CWT_POLYR_CASE(2) CWT_POLYR_CASE(4) CWT_POLYR_CASE(6) CWT_POLYR_CASE(8) CWT_POLYR_CASE(10) CWT_POLYR_CASE(12)
     CWT_POLYR_CASE(14) CWT_POLYR_CASE(16) CWT_POLYR_CASE(18) CWT_POLYR_CASE(20) CWT_POLYR_CASE(22) CWT_POLYR_CASE(24)
