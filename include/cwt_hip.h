@@ -119,6 +119,9 @@ int cwt_plan_set_stream(cwt_plan* plan, void* hip_stream);
  *   "ols_small_big" 0 = rows with a halo in ("ols_small_max_halo", 1024] on the default tile (default 1: on 8192-point blocks of TWO
  *                  half-size tiles each where the block support is <= 512 bins -- 256-thread workgroups, four per CU, instead of one
  *                  512-thread workgroup per block, two per CU: fp64 Morlet / DOG -0.3 ... -0.8 %, fp32 DOG -2 % of the step)
+ *   "aols_long"    0 = precision 64: rows clipped at Nyquist whose kernel needs a halo of 512 ... 2048 samples stay two-pass rows (default
+ *                  1: the second, 8192-point class of the rows on the band-passed signal takes them -- fp64 Paul, scales of 2 ... 5
+ *                  samples: 16 of its 36 two-pass rows, -3.7 % of the step)
  *   "ols_min_logn" log2 of the shortest transform length that uses the form (default 18; tests lower it to 15)
  *   "ols_side", "ols_early" 0 = queue the block spectra / the whole overlap-save chain on the plan's own stream instead
  *                  of a side stream beside the forward FFT and the two-pass chain (defaults 1)

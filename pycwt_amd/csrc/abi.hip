@@ -370,6 +370,7 @@ int cwt_plan_set_option(cwt_plan* p, const char* key, int64_t value) {
   else if (k == "host_direct") p->host_direct = value != 0;
   else if (k == "aols") p->aols = value != 0;
   else if (k == "aols_zc") p->aols_zc = value != 0;
+  else if (k == "aols_long") p->aols_long = value != 0;
   else if (k == "poly") p->poly = value != 0;
   else if (k == "coef_small") p->coef_small = value != 0;
   else if (k == "poly_carrier") p->poly_carrier = value != 0;

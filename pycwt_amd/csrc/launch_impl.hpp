@@ -942,9 +942,11 @@ int fill_aols_tables(cwt_plan* p, const Mother& mo) {
   if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
   else if (mo.kind == MOTHER_PAUL) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
   else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_DOG>), grid, block, 0, p->stream, rows, mo, t->aols_logp, t->aols_geom, gt);
-  if (t->n_aols2)      // the second class (Paul, 8192-point tiles): its rows carry the offsets of their tables behind the first's
-    hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), dim3((1 << 13) / 256, t->aols2_geom.nrows), block, 0, p->stream,
-                       t->rows_dev + t->aols2_first, mo, 13, t->aols2_geom, gt);
+  if (t->n_aols2) {    // the second class (8192-point tiles): its rows carry the offsets of their tables behind the first's
+    const dim3 grid2((1 << 13) / 256, t->aols2_geom.nrows);
+    if (mo.kind == MOTHER_MORLET) hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_MORLET>), grid2, block, 0, p->stream, t->rows_dev + t->aols2_first, mo, 13, t->aols2_geom, gt);
+    else hipLaunchKernelGGL((k_aols_gtab<T, MOTHER_PAUL>), grid2, block, 0, p->stream, t->rows_dev + t->aols2_first, mo, 13, t->aols2_geom, gt);
+  }
   HIPCHECK(hipGetLastError());
   return CWT_OK;
 }

@@ -106,6 +106,7 @@ struct cwt_plan {
                            // HIP graph on its second occurrence and replay it from the third on
   int aols = 1;            // rows clipped at Nyquist as overlap-save rows on the band-passed complex signal (k_aols_*)
   int aols_zc = 1;         // Paul rows not clipped at Nyquist on the band-passed signal too, their profile continued through f = 0
+  int aols_long = 1;       // complex128: clipped rows with halos of 512 ... 2048 samples in the second (8192-point) class of the band-passed rows
   int aols_min_rows = 3;   // ... if at least this many rows qualify (the band-passed signal costs about one two-pass row)
   int serial_rows = 2;     // (complex128; complex64 plans start at 0: measured +-0 ... +1.5 % there) long transforms with polynomial rows: every kernel that writes W on the caller's stream, one after the
                            // other, the preparation on the side streams (rows_launch_serial); 2 = also the first block spectra on the

@@ -825,6 +825,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
       const double eps = std::max(tol.halo, p->prec == 64 ? 2e-14 : 5e-7);
       std::vector<int> halo_of_scale(size_t(rps), -1);     // (a numeric tail search each: once per scale, not per signal)
       const std::vector<double> window = aols_window_grid(ag, 512);
+      std::vector<double> window2;                          // ... on the grid of the long-halo search (made when a row asks for it)
       ag.zc_c = ag2.zc_c = zc_c;
       ag.zc_w = ag2.zc_w = zc_c / 6.0;
       double zc_f_safe = 0, zc_factor = 0, zc_dummy = 0;
@@ -860,6 +861,13 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
         if (h < 0) h = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 512, window);
         halos[i] = h;
         if (halos[i]) { ++cnt; hmax_seen = std::max(hmax_seen, halos[i]); }
+        else if (p->aols_long && p->prec == 64 && rows_per_signal == 0 && mother != MOTHER_DOG && p->logN >= 16) {
+          // clipped rows whose kernel is longer than the 4096-point tile allows (fp64 Paul, s = 2.2 ... 11: the kink of f^m H(f) at
+          // f = 0 with no room for the continuation through it): the second class, 8192-point tiles, halos up to 2048
+          if (window2.empty()) window2 = aols_window_grid(ag, 2048);
+          const int h2 = aols_halo(mother, param, wide_rows[i].a * double(N), ag, eps, 2048, window2);
+          if (h2 > 512) { halos2[i] = h2; ++cnt2; hmax2_seen = std::max(hmax2_seen, h2); }
+        }
       }
       if (cnt2 && !cnt) {                                  // (the second class rides on the first one's band-passed signal: keep
         cnt2 = 0;                                          // the layout simple -- no first class, no second)
@@ -893,7 +901,7 @@ int build_row_table(cwt_plan* p, int mother, double param, const double* a, cons
           o.k_lo = ag2.ksp; o.nband = P2;
           o.logK = 13; o.nterms = 1;
           o.nyq_re = o.nyq_im = 0.0;
-          o.aux_off = 1;
+          o.aux_off = zc_row[i] ? 1 : 0;                    // continued through f = 0, or the plain window of the first class
           o.tab_off = toff2;
           toff2 += P2;
           aols2_rows.push_back(o);

@@ -374,3 +374,24 @@ def test_filter_rows_takes_the_polynomial_form_with_its_weight_tables(emu_librar
     for b in (Xd, spec, out):
         b.free()
     plan.close()
+
+
+def test_clipped_paul_rows_with_long_halos_on_the_second_tile_class(emu_library, monkeypatch):
+    """complex128 Paul, scales of 2 ... 5 samples: the filter is cut at Nyquist AND the kink at f = 0 leaves a 1/t^5 tail with no room for the
+    continuation through it -- halos of 512 ... 2048 samples.  Option aols_long (default): the second, 8192-point class of the rows on the
+    band-passed signal takes them (plain window, not the continuation), where they were two-pass rows."""
+    monkeypatch.delenv("CWT_TOLERANCE", raising=False)
+    N = 1 << 16
+    n0 = N - 33
+    m = orc.Mother(orc.PAUL, 4)
+    sj = np.geomspace(1.5, 12.0, 28)
+    x = np.random.default_rng(78).standard_normal(n0)
+    ref = orc.cwt_rows(x, 1.0, sj, m, N=N, intended=True)[:, :n0]
+    opts = {"ols_min_logn": 15, "poly_min_logn": 15, "tolerance": 1e-9}
+    W, split, classes = transform(emu_library, N, x, orc.PAUL, 4, sj, 64, opts)
+    W0, split0, classes0 = transform(emu_library, N, x, orc.PAUL, 4, sj, 64, dict(opts, aols_long=0))
+    moved = [j for j, (a, b) in enumerate(zip(classes, classes0)) if a == "aols/P8192" and b.startswith("two_pass")]
+    assert len(moved) >= 4, (sorted(set(classes)), sorted(set(classes0)))
+    per_row = row_errors(W, ref)[0]
+    assert per_row.max() < 1e-9, (per_row.argmax(), classes[per_row.argmax()], per_row.max())
+    assert row_errors(W[moved], W0[moved])[0].max() < 1e-9
